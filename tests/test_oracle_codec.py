@@ -1,0 +1,119 @@
+"""Codec-level pins of the oracle: hand-traced streams, the src/lib.rs:23-39
+doc-test, the tests/corpora.rs round-trip contract (identity + returned counts == lengths)
+for every corpus file x {Linear, Tree} x freq bits {14,22,30}, linear-stream == tree-stream,
+the committed golden tables, and C oracle == independent Python restatement."""
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+from conftest import GOLDEN, corpus_files
+from oracle import cbind as ox
+from oracle import redux_ref as rr
+
+WIDTHS = [(8, 14, 16), (8, 22, 24), (8, 30, 32)]
+
+HAND_TRACED = [  # traced on paper from codec.rs / adaptive_tree.rs, not produced by any code
+    (b"", (8, 14, 16), "ff00", (0, 2)),
+    (b"", (8, 30, 32), "ff00ff00", (0, 4)),
+    (b"\x61", (8, 14, 16), "619d02", (1, 3)),
+    (b"\x61", (8, 30, 32), "619d64970e", (1, 5)),
+]
+
+
+@pytest.mark.parametrize("data,params,hexs,counts", HAND_TRACED)
+def test_hand_traced_vectors(data, params, hexs, counts):
+    s, c = ox.compress(data, params, ox.TREE)
+    assert s.hex() == hexs and c == counts
+    s2, c2 = rr.compress(data, rr.AdaptiveTreeModel(rr.Parameters(*params)))
+    assert s2.hex() == hexs and c2 == counts
+    s3, _ = ox.compress(data, params, ox.LINEAR)
+    assert s3.hex() == hexs
+    d, dc = ox.decompress(s, params, ox.TREE)
+    assert d == data and dc == (counts[1], counts[0])
+
+
+def test_doctest_roundtrip():  # src/lib.rs:23-39
+    data = bytes([0x72, 0x65, 0x64, 0x75, 0x78])
+    s, c = ox.compress(data, (8, 14, 16), ox.TREE)
+    assert c == (5, len(s))
+    d, dc = ox.decompress(s, (8, 14, 16), ox.TREE)
+    assert d == data and dc == (len(s), 5)
+
+
+@pytest.mark.parametrize("key,path", corpus_files("artificial", "calgary", "canterbury", "large", "misc"))
+def test_corpus_roundtrip_tree_and_golden(key, path):  # tests/corpora.rs:32-85 (Tree rows)
+    data = open(path, "rb").read()
+    gold = json.load(open(os.path.join(GOLDEN, "blocks.json")))[key]
+    for w in WIDTHS:
+        s, c = ox.compress(data, w, ox.TREE)
+        assert c == (len(data), len(s))  # corpora.rs:40-41
+        d, dc = ox.decompress(s, w, ox.TREE, cap=len(data) + 16)
+        assert d == data and dc == (len(s), len(data))  # corpora.rs:59-61
+        g = gold["%d_%d_%d" % w]
+        assert len(s) == g["whole_size"]
+        assert hashlib.blake2b(s, digest_size=8).hexdigest() == g["whole_hash"]
+
+
+@pytest.mark.parametrize("key,path", corpus_files("artificial", "calgary", "canterbury"))
+def test_corpus_linear_equals_tree(key, path):  # tests/corpora.rs Linear rows + SURVEY 8c cross-check (1)
+    data = open(path, "rb").read()[:200000]  # the O(N) linear model is slow; a 200 kB prefix per file
+    for w in WIDTHS:
+        st, ct = ox.compress(data, w, ox.TREE)
+        sl, cl = ox.compress(data, w, ox.LINEAR)
+        assert st == sl and ct == cl
+        d, _ = ox.decompress(sl, w, ox.LINEAR, cap=len(data) + 16)
+        assert d == data
+
+
+def test_golden_block_tables():
+    gold = json.load(open(os.path.join(GOLDEN, "blocks.json")))
+    manifest = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    for key in ["canterbury/alice29.txt", "calgary/geo", "artificial/aaa.txt", "calgary/pic"]:
+        data = open(os.path.join(GOLDEN, "corpora", key), "rb").read()
+        assert hashlib.md5(data).hexdigest() == manifest[key]["md5"]
+        for w in WIDTHS:
+            streams, status = ox.compress_blocks(data, 65536, w, ox.TREE, nthreads=4)
+            assert not status.any()
+            g = gold[key]["%d_%d_%d" % w]
+            assert [len(s) for s in streams] == g["block_sizes"]
+            assert [hashlib.blake2b(s, digest_size=8).hexdigest() for s in streams] == g["block_hashes"]
+            # each block is exactly redux::compress(block)
+            b0, _ = ox.compress(data[:65536], w, ox.TREE)
+            assert streams[0] == b0
+
+
+def test_kat_streams_file():
+    for k in json.load(open(os.path.join(GOLDEN, "kat_streams.json"))):
+        data = bytes.fromhex(k["input_hex"])
+        s, c = ox.compress(data, tuple(k["params"]), ox.TREE)
+        assert s.hex() == k["stream_hex"] and list(c) == k["counts"]
+
+
+def test_c_equals_python_restatement():
+    rnd = random.Random(11)
+    alice = open(os.path.join(GOLDEN, "corpora", "canterbury", "alice29.txt"), "rb").read()
+    cases = [alice[:3000], bytes(rnd.randrange(256) for _ in range(2500)), b"a" * 3000, bytes(range(256)) * 4,
+             bytes(rnd.choice(b"ab") for _ in range(3000))]
+    for data in cases:
+        for w in WIDTHS + [(8, 10, 16)]:  # (8,10,16) freezes after 766 symbols
+            s, c = ox.compress(data, w, ox.TREE)
+            s2, c2 = rr.compress(data, rr.AdaptiveTreeModel(rr.Parameters(*w)))
+            assert s == s2 and c == c2
+            d2, dc2 = rr.decompress(s, rr.AdaptiveTreeModel(rr.Parameters(*w)))
+            assert d2 == data and dc2 == (len(s), len(data))
+
+
+def test_truncated_and_overlong_streams():
+    data = open(os.path.join(GOLDEN, "corpora", "canterbury", "xargs.1"), "rb").read()
+    s, _ = ox.compress(data, (8, 30, 32))
+    with pytest.raises(ox.OracleError) as e:  # bitio/mod.rs:107 via codec.rs:50
+        ox.decompress(s[: len(s) // 2], (8, 30, 32))
+    assert e.value.status == ox.EOF
+    with pytest.raises(ox.OracleError) as e:  # bounded sink => IoError
+        ox.decompress(s, (8, 30, 32), cap=100)
+    assert e.value.status == ox.IO_ERROR
+    d, dc = ox.decompress(s + b"\x00\x00junk", (8, 30, 32))  # trailing bytes are never read
+    assert d == data and dc[0] == len(s)
