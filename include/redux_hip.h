@@ -1,0 +1,136 @@
+/*
+ * redux_hip.h -- C ABI of the MI355X-native block coder that sits behind peterbudai/redux's
+ * compress / decompress surface.  Plain pointers and sizes only; no HIP or torch types.
+ *
+ * Every entry point names the reference interface it replaces (file:line under the
+ * reference checkout).  The reference-side binding a maintainer would add (Rust
+ * `extern "C"` block + safe wrappers) is shown in INTEGRATION.md.
+ *
+ * Semantics shared by all calls
+ *   - A "block" is block_size consecutive input bytes (the last one may be shorter; an
+ *     empty input is ONE empty block).  Each block is coded by a fresh Codec + fresh
+ *     AdaptiveTreeModel, so block b's stream is byte-identical to
+ *     redux::compress(&mut &in[b*block_size..], .., AdaptiveTreeModel::new(params))
+ *     (src/lib.rs:102, src/codec.rs:104, src/model/adaptive_tree.rs:36).
+ *   - Status codes mirror src/lib.rs:57-64: 0 Ok, 1 Eof, 2 InvalidInput, 3 IoError (here: a
+ *     HIP runtime failure), plus 4 OutputTooSmall and 5 Unsupported (parameters the device
+ *     path does not implement: symbol_bits != 8 or code_bits > 32).  There is NO CPU
+ *     fallback: Unsupported is returned, never silently served by other code.
+ *   - The caller owns every buffer.  Host-pointer calls are synchronous.  `_dev` calls take
+ *     device pointers, enqueue on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream), never allocate, never synchronise and keep no pointer after they return.
+ *   - Re-entrant: no global mutable state.
+ */
+#ifndef REDUX_HIP_H
+#define REDUX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/lib.rs:57-64 enum Error (+ two codes the block API needs) */
+enum {
+    REDUX_OK               = 0,
+    REDUX_EOF              = 1, /* Error::Eof: compressed input ended early (bitio/mod.rs:107) */
+    REDUX_INVALID_INPUT    = 2, /* Error::InvalidInput (model/mod.rs:65, adaptive_tree.rs:131) */
+    REDUX_IO_ERROR         = 3, /* Error::IoError: here a HIP runtime error */
+    REDUX_OUTPUT_TOO_SMALL = 4, /* the caller's output buffer / slot cannot hold the result */
+    REDUX_UNSUPPORTED      = 5  /* valid Parameters the device path does not implement */
+};
+
+/* The three integers of model::Parameters::new (src/model/mod.rs:63); the library derives
+ * the other eight fields (mod.rs:67-79) itself. */
+typedef struct redux_params {
+    uint32_t symbol_bits; /* 8 on the device path */
+    uint32_t freq_bits;
+    uint32_t code_bits;   /* <= 32 on the device path */
+} redux_params;
+
+/* model::Parameters::new validation, src/model/mod.rs:64: OK or INVALID_INPUT. */
+int redux_params_check(uint32_t symbol_bits, uint32_t freq_bits, uint32_t code_bits);
+/* OK, INVALID_INPUT, or UNSUPPORTED for valid triples outside the device path. */
+int redux_device_supports(const redux_params *p);
+
+/* Geometry of the block API. */
+uint64_t redux_block_count(uint64_t in_len, uint32_t block_size); /* max(1, ceil(in_len / block_size)) */
+/* Worst-case bytes of one block's stream for these parameters (9 bits/symbol while the model
+ * cannot freeze inside a block, freq_bits+2 bits/symbol once it can, + 1 KiB). */
+uint64_t redux_encode_slot_bytes(const redux_params *p, uint32_t block_size);
+/* Dense-output capacity that always suffices: block_count * slot_bytes. */
+uint64_t redux_encode_bound(const redux_params *p, uint64_t in_len, uint32_t block_size);
+uint64_t redux_encode_workspace_bytes(const redux_params *p, uint64_t in_len, uint32_t block_size);
+uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, uint32_t block_size);
+
+/* ---- host-pointer, synchronous ------------------------------------------------------
+ * redux_encode_blocks: replaces one redux::compress call per block (src/lib.rs:102-109).
+ *   out          dense concatenation of the per-block streams
+ *   out_offsets  nblocks+1 entries; block b's stream is out[out_offsets[b] .. out_offsets[b+1])
+ *                (so (bytes_in, bytes_out) of lib.rs:108 = (block length, offsets[b+1]-offsets[b]))
+ *   block_status nblocks entries, per-block status (may be NULL)
+ * Returns the first non-OK per-block status, or a call-level error. */
+int redux_encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_len, uint32_t block_size,
+                        uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status);
+
+/* redux_decode_blocks: replaces one redux::decompress call per block (src/lib.rs:113-120).
+ *   in / in_offsets  dense streams as produced by redux_encode_blocks
+ *   out              block b is written at out + b*block_size (at most block_size bytes)
+ *   out_sizes        nblocks entries: decoded length of each block
+ * Per-block status: EOF for a truncated stream, INVALID_INPUT for a code value outside the
+ * model's total, OUTPUT_TOO_SMALL if a (corrupt) stream decodes past block_size. */
+int redux_decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
+                        uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes,
+                        int32_t *block_status);
+
+/* Whole-stream drop-ins for redux::compress / redux::decompress (src/lib.rs:102,113): the
+ * input is ONE block of any length, so the stream equals the reference's for the same bytes.
+ * One coder = one GPU lane: correct but serial; the block API is the accelerated path.
+ * bytes_in / bytes_out are the (u64,u64) the reference returns. */
+int redux_compress(const redux_params *p, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
+                   uint64_t *bytes_in, uint64_t *bytes_out);
+int redux_decompress(const redux_params *p, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
+                     uint64_t *bytes_in, uint64_t *bytes_out);
+
+/* ---- device-pointer, stream-ordered --------------------------------------------------
+ * Same contracts with every pointer in device memory.  d_workspace must hold
+ * redux_encode_workspace_bytes() / redux_decode_workspace_bytes() bytes and be 256-B aligned.
+ * d_summary (int32[2], may be NULL): [0] = first non-OK status over all blocks (0 if none),
+ * [1] = number of non-OK blocks.  Errors found on the device are reported there and in
+ * d_block_status; the return value covers argument and launch errors only. */
+int redux_encode_blocks_dev(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size,
+                            void *d_out, uint64_t out_cap, void *d_out_offsets /* u64[nblocks+1] */,
+                            void *d_block_status /* i32[nblocks] */, void *d_summary /* i32[2] */,
+                            void *d_workspace, uint64_t workspace_bytes, void *stream);
+int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void *d_in_offsets /* u64[nblocks+1] */,
+                            uint64_t nblocks, uint32_t block_size, void *d_out, uint64_t out_cap,
+                            void *d_out_sizes /* u32[nblocks] */, void *d_block_status, void *d_summary,
+                            void *d_workspace, uint64_t workspace_bytes, void *stream);
+
+/* The two phases of redux_encode_blocks_dev, exposed so a harness can time the coder kernel
+ * by itself: (1) code every block into its padded slot inside the workspace and record the
+ * sizes; (2) scan the sizes and gather the slots into the dense output. */
+int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size,
+                           void *d_block_status, void *d_workspace, uint64_t workspace_bytes, void *stream);
+int redux_compact_slots_dev(const redux_params *p, uint64_t in_len, uint32_t block_size, void *d_out, uint64_t out_cap,
+                            void *d_out_offsets, void *d_block_status, void *d_summary,
+                            void *d_workspace, uint64_t workspace_bytes, void *stream);
+
+/* ---- synthetic workloads of BASELINE.json, generated in HBM ----------
+ * iid : byte j = byte (j mod 8), little-endian, of splitmix64(seed + j/8).
+ * zipf: byte j = rank-1 where rank is drawn by inverse CDF of P(r) ~ r^-1.2, r = 1..256,
+ *       from the high 32 bits of splitmix64(seed + j) against the 256-entry u32 table
+ *       returned by redux_zipf_thresholds() (thresholds[r-1] = floor(2^32 * CDF(r)) , last = 2^32-1).
+ * first_byte lets a rank generate its own shard: byte j of the call is stream byte first_byte + j. */
+int redux_gen_iid_dev(void *d_out, uint64_t len, uint64_t first_byte, uint64_t seed, void *stream);
+int redux_gen_zipf_dev(void *d_out, uint64_t len, uint64_t first_byte, uint64_t seed, void *stream);
+const uint32_t *redux_zipf_thresholds(void);
+
+/* Library / build identification: "redux_hip <version> gfx950". */
+const char *redux_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

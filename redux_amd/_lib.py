@@ -1,0 +1,63 @@
+"""ctypes loader of the C ABI declared in include/redux_hip.h.
+
+There is no fallback of any kind: if libredux_hip.so is missing or a symbol is absent this
+module raises, and every public function of redux_amd fails with it.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libredux_hip.so")
+
+OK, EOF, INVALID_INPUT, IO_ERROR, OUTPUT_TOO_SMALL, UNSUPPORTED = 0, 1, 2, 3, 4, 5
+
+
+class Params(C.Structure):
+    _fields_ = [("symbol_bits", C.c_uint32), ("freq_bits", C.c_uint32), ("code_bits", C.c_uint32)]
+
+
+_PP = C.POINTER(Params)
+_V = C.c_void_p
+_U64 = C.c_uint64
+_U32 = C.c_uint32
+
+# name -> (restype, argtypes): exactly the declarations of include/redux_hip.h
+SIGNATURES = {
+    "redux_version": (C.c_char_p, []),
+    "redux_params_check": (C.c_int, [_U32, _U32, _U32]),
+    "redux_device_supports": (C.c_int, [_PP]),
+    "redux_block_count": (_U64, [_U64, _U32]),
+    "redux_encode_slot_bytes": (_U64, [_PP, _U32]),
+    "redux_encode_bound": (_U64, [_PP, _U64, _U32]),
+    "redux_encode_workspace_bytes": (_U64, [_PP, _U64, _U32]),
+    "redux_decode_workspace_bytes": (_U64, [_PP, _U64, _U32]),
+    "redux_encode_blocks": (C.c_int, [_PP, _V, _U64, _U32, _V, _U64, _V, _V]),
+    "redux_decode_blocks": (C.c_int, [_PP, _V, _V, _U64, _U32, _V, _U64, _V, _V]),
+    "redux_compress": (C.c_int, [_PP, _V, _U64, _V, _U64, C.POINTER(_U64), C.POINTER(_U64)]),
+    "redux_decompress": (C.c_int, [_PP, _V, _U64, _V, _U64, C.POINTER(_U64), C.POINTER(_U64)]),
+    "redux_encode_blocks_dev": (C.c_int, [_PP, _V, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
+    "redux_decode_blocks_dev": (C.c_int, [_PP, _V, _V, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
+    "redux_encode_slots_dev": (C.c_int, [_PP, _V, _U64, _U32, _V, _V, _U64, _V]),
+    "redux_compact_slots_dev": (C.c_int, [_PP, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
+    "redux_gen_iid_dev": (C.c_int, [_V, _U64, _U64, _U64, _V]),
+    "redux_gen_zipf_dev": (C.c_int, [_V, _U64, _U64, _U64, _V]),
+    "redux_zipf_thresholds": (C.POINTER(_U32), []),
+}
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m redux_amd.build` "
+                "(there is no CPU fallback for the redux hot path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the library does not export it
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB

@@ -1,0 +1,338 @@
+"""Host-side mirror of the reference's public interface for the block-coding path.
+
+Reference surface (file:line under the reference checkout) and what stands for it here:
+  redux::Error / Result            src/lib.rs:57-98      -> Error, Eof, InvalidInput, IoError
+  model::Parameters::new           src/model/mod.rs:63   -> Parameters(symbol, frequency, code)
+  model::AdaptiveTreeModel::new    adaptive_tree.rs:36   -> AdaptiveTreeModel(params)
+  redux::compress / decompress     src/lib.rs:102,113    -> compress / decompress (file-like in, file-like out)
+  (new) block API                  SURVEY.md 8(b)        -> compress_blocks / decompress_blocks,
+                                                            DeviceEncoder / DeviceDecoder (HBM-resident)
+
+Every byte of every stream is produced by the gfx950 kernels behind include/redux_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Params as _CParams
+
+
+# ---- src/lib.rs:57-98 -------------------------------------------------------------------
+class Error(Exception):
+    """redux::Error"""
+    status = None
+
+
+class Eof(Error):
+    """Error::Eof -- "Unexpected end of file" (src/lib.rs:69)"""
+    status = _lib.EOF
+
+    def __str__(self):
+        return "Unexpected end of file"
+
+
+class InvalidInput(Error):
+    """Error::InvalidInput (src/lib.rs:70)"""
+    status = _lib.INVALID_INPUT
+
+    def __str__(self):
+        return "Invalid data found while processing input"
+
+
+class IoError(Error):
+    """Error::IoError -- on this path: a HIP runtime failure"""
+    status = _lib.IO_ERROR
+
+
+class OutputTooSmall(IoError):
+    status = _lib.OUTPUT_TOO_SMALL
+
+
+class Unsupported(Error):
+    """Valid Parameters that the device path does not implement (no CPU fallback exists)."""
+    status = _lib.UNSUPPORTED
+
+
+_BY_STATUS = {c.status: c for c in (Eof, InvalidInput, IoError, OutputTooSmall, Unsupported)}
+
+
+def _raise(status, what=""):
+    if status != _lib.OK:
+        raise _BY_STATUS.get(status, Error)(what or f"status {status}")
+
+
+# ---- src/model/mod.rs:32-81 -------------------------------------------------------------
+class Parameters:
+    """model::Parameters: same eleven fields, same validation rule (mod.rs:64)."""
+
+    def __init__(self, symbol, frequency, code):
+        if _lib.lib().redux_params_check(symbol, frequency, code) != _lib.OK:
+            raise InvalidInput()
+        self.symbol_bits = symbol
+        self.symbol_eof = 1 << symbol
+        self.symbol_count = (1 << symbol) + 1
+        self.freq_bits = frequency
+        self.freq_max = (1 << frequency) - 1
+        self.code_bits = code
+        self.code_min = 0
+        self.code_one_fourth = 1 << (code - 2)
+        self.code_half = 2 << (code - 2)
+        self.code_three_fourths = 3 << (code - 2)
+        self.code_max = (1 << code) - 1
+
+    @classmethod
+    def new(cls, symbol, frequency, code):
+        return cls(symbol, frequency, code)
+
+    def _c(self):
+        return _CParams(self.symbol_bits, self.freq_bits, self.code_bits)
+
+    def triple(self):
+        return (self.symbol_bits, self.freq_bits, self.code_bits)
+
+
+class AdaptiveTreeModel:
+    """model::AdaptiveTreeModel::new(Parameters) -- the model the device implements.  The
+    object only carries the parameters: the tree itself lives in LDS, one per block."""
+
+    def __init__(self, params):
+        self.params = params
+
+    @classmethod
+    def new(cls, params):
+        return cls(params)
+
+    def parameters(self):
+        return self.params
+
+
+def _params_of(model_or_params):
+    if isinstance(model_or_params, AdaptiveTreeModel):
+        return model_or_params.params
+    if isinstance(model_or_params, Parameters):
+        return model_or_params
+    if isinstance(model_or_params, (tuple, list)):
+        return Parameters(*model_or_params)
+    raise TypeError("expected Parameters, AdaptiveTreeModel or a (symbol, frequency, code) triple")
+
+
+def version():
+    return _lib.lib().redux_version().decode()
+
+
+def _u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+def _ptr(a):
+    return a.ctypes.data if a.size else None
+
+
+# ---- block API, host buffers ------------------------------------------------------------
+def compress_blocks(data, block_size, params=(8, 30, 32)):
+    """Per-block redux::compress on the GPU.  Returns (dense streams as uint8 array,
+    offsets uint64[nblocks+1], status int32[nblocks]); raises on the first non-OK block."""
+    P = _params_of(params)
+    a = _u8(data)
+    L = _lib.lib()
+    cp = P._c()
+    _raise(L.redux_device_supports(C.byref(cp)))
+    if block_size <= 0:
+        raise InvalidInput()
+    nb = L.redux_block_count(len(a), block_size)
+    cap = L.redux_encode_bound(C.byref(cp), len(a), block_size)
+    out = np.empty(cap, dtype=np.uint8)
+    offs = np.zeros(nb + 1, dtype=np.uint64)
+    status = np.zeros(nb, dtype=np.int32)
+    st = L.redux_encode_blocks(C.byref(cp), _ptr(a), len(a), block_size, out.ctypes.data, cap, offs.ctypes.data,
+                               status.ctypes.data)
+    _raise(st)
+    return out[: int(offs[-1])], offs, status
+
+
+def decompress_blocks(streams, offsets, block_size, params=(8, 30, 32), check=True):
+    """Per-block redux::decompress on the GPU.  Returns (out uint8[nblocks*block_size],
+    sizes uint32[nblocks], status int32[nblocks]); block b occupies out[b*block_size:][:sizes[b]]."""
+    P = _params_of(params)
+    a = _u8(streams)
+    offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+    nb = len(offs) - 1
+    L = _lib.lib()
+    cp = P._c()
+    _raise(L.redux_device_supports(C.byref(cp)))
+    out = np.empty(nb * block_size, dtype=np.uint8)
+    sizes = np.zeros(nb, dtype=np.uint32)
+    status = np.zeros(nb, dtype=np.int32)
+    st = L.redux_decode_blocks(C.byref(cp), _ptr(a), offs.ctypes.data, nb, block_size, out.ctypes.data, out.size,
+                               sizes.ctypes.data, status.ctypes.data)
+    if check:
+        _raise(st)
+    return out, sizes, status
+
+
+# ---- src/lib.rs:102-120: whole-stream drop-ins --------------------------------------------
+def compress(istream, ostream, model):
+    """redux::compress(istream, ostream, model) -> (bytes_in, bytes_out).  The whole input is
+    one block, so the stream equals the reference's; it is coded by one GPU lane."""
+    P = _params_of(model)
+    a = _u8(istream.read())
+    L = _lib.lib()
+    cp = P._c()
+    cap = L.redux_encode_bound(C.byref(cp), len(a), max(len(a), 1))
+    _raise(L.redux_device_supports(C.byref(cp)))
+    out = np.empty(cap, dtype=np.uint8)
+    bi, bo = C.c_uint64(), C.c_uint64()
+    _raise(L.redux_compress(C.byref(cp), _ptr(a), len(a), out.ctypes.data, cap, C.byref(bi), C.byref(bo)))
+    ostream.write(out[: bo.value].tobytes())
+    return (bi.value, bo.value)
+
+
+def decompress(istream, ostream, model, max_output=None):
+    """redux::decompress(istream, ostream, model) -> (bytes_in, bytes_out)."""
+    P = _params_of(model)
+    a = _u8(istream.read())
+    L = _lib.lib()
+    cp = P._c()
+    _raise(L.redux_device_supports(C.byref(cp)))
+    cap = max_output if max_output is not None else max(64 * len(a), 1 << 20)
+    out = np.empty(cap, dtype=np.uint8)
+    bi, bo = C.c_uint64(), C.c_uint64()
+    _raise(L.redux_decompress(C.byref(cp), _ptr(a), len(a), out.ctypes.data, cap, C.byref(bi), C.byref(bo)))
+    ostream.write(out[: bo.value].tobytes())
+    return (bi.value, bo.value)
+
+
+# ---- block API, HBM-resident (torch only provides memory + streams) ------------------------
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("redux_amd device API needs a GPU (torch.cuda.is_available() is False)")
+    return torch
+
+
+def _stream_ptr(torch):
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeviceEncoder:
+    """Reusable encoder for inputs of up to max_in_len bytes already resident in HBM.
+    Allocates once (workspace, dense output, offsets, status); encode() only enqueues kernels
+    on torch's current stream."""
+
+    def __init__(self, params, block_size, max_in_len, device="cuda:0"):
+        torch = _torch()
+        self.P = _params_of(params)
+        self.cp = self.P._c()
+        L = _lib.lib()
+        _raise(L.redux_device_supports(C.byref(self.cp)))
+        self.block_size = int(block_size)
+        self.max_in_len = int(max_in_len)
+        self.nblocks_max = L.redux_block_count(self.max_in_len, self.block_size)
+        self.ws_bytes = L.redux_encode_workspace_bytes(C.byref(self.cp), self.max_in_len, self.block_size)
+        self.out_cap = L.redux_encode_bound(C.byref(self.cp), self.max_in_len, self.block_size)
+        self.device = torch.device(device)
+        self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        self.ws_off = (-self.ws.data_ptr()) % 256
+        self.out = torch.empty(self.out_cap, dtype=torch.uint8, device=self.device)
+        self.offsets = torch.zeros(self.nblocks_max + 1, dtype=torch.int64, device=self.device)
+        self.status = torch.zeros(self.nblocks_max, dtype=torch.int32, device=self.device)
+        self.summary = torch.zeros(2, dtype=torch.int32, device=self.device)
+
+    def _ws_ptr(self):
+        return C.c_void_p(self.ws.data_ptr() + self.ws_off)
+
+    def encode_slots(self, d_in):
+        """Phase 1 only: the coder kernel (padded slots + sizes inside the workspace)."""
+        torch = _torch()
+        n = d_in.numel()
+        assert d_in.dtype == torch.uint8 and d_in.is_contiguous() and n <= self.max_in_len
+        st = _lib.lib().redux_encode_slots_dev(C.byref(self.cp), C.c_void_p(d_in.data_ptr()), n, self.block_size,
+                                               C.c_void_p(self.status.data_ptr()), self._ws_ptr(), self.ws_bytes,
+                                               _stream_ptr(torch))
+        _raise(st)
+
+    def compact(self, n):
+        """Phase 2 only: scan + gather into the dense output."""
+        torch = _torch()
+        self.summary.zero_()
+        st = _lib.lib().redux_compact_slots_dev(C.byref(self.cp), n, self.block_size, C.c_void_p(self.out.data_ptr()),
+                                                self.out_cap, C.c_void_p(self.offsets.data_ptr()),
+                                                C.c_void_p(self.status.data_ptr()),
+                                                C.c_void_p(self.summary.data_ptr()), self._ws_ptr(), self.ws_bytes,
+                                                _stream_ptr(torch))
+        _raise(st)
+
+    def encode(self, d_in):
+        """Full pass, stream-ordered: returns (out, offsets[nblocks+1], status, summary) views
+        of this encoder's buffers (valid until the next call)."""
+        torch = _torch()
+        n = d_in.numel()
+        assert d_in.dtype == torch.uint8 and d_in.is_contiguous() and n <= self.max_in_len
+        self.summary.zero_()
+        st = _lib.lib().redux_encode_blocks_dev(C.byref(self.cp), C.c_void_p(d_in.data_ptr()), n, self.block_size,
+                                                C.c_void_p(self.out.data_ptr()), self.out_cap,
+                                                C.c_void_p(self.offsets.data_ptr()), C.c_void_p(self.status.data_ptr()),
+                                                C.c_void_p(self.summary.data_ptr()), self._ws_ptr(), self.ws_bytes,
+                                                _stream_ptr(torch))
+        _raise(st)
+        nb = _lib.lib().redux_block_count(n, self.block_size)
+        return self.out, self.offsets[: nb + 1], self.status[:nb], self.summary
+
+
+class DeviceDecoder:
+    """Reusable decoder for up to max_blocks blocks resident in HBM."""
+
+    def __init__(self, params, block_size, max_blocks, device="cuda:0"):
+        torch = _torch()
+        self.P = _params_of(params)
+        self.cp = self.P._c()
+        L = _lib.lib()
+        _raise(L.redux_device_supports(C.byref(self.cp)))
+        self.block_size = int(block_size)
+        self.max_blocks = int(max_blocks)
+        self.ws_bytes = L.redux_decode_workspace_bytes(C.byref(self.cp), self.max_blocks, self.block_size)
+        self.device = torch.device(device)
+        self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        self.ws_off = (-self.ws.data_ptr()) % 256
+        self.out = torch.empty(self.max_blocks * self.block_size, dtype=torch.uint8, device=self.device)
+        self.sizes = torch.zeros(self.max_blocks, dtype=torch.int32, device=self.device)
+        self.status = torch.zeros(self.max_blocks, dtype=torch.int32, device=self.device)
+        self.summary = torch.zeros(2, dtype=torch.int32, device=self.device)
+
+    def decode(self, d_streams, d_offsets):
+        torch = _torch()
+        nb = d_offsets.numel() - 1
+        assert nb <= self.max_blocks and d_offsets.dtype == torch.int64 and d_streams.dtype == torch.uint8
+        self.summary.zero_()
+        st = _lib.lib().redux_decode_blocks_dev(C.byref(self.cp), C.c_void_p(d_streams.data_ptr()),
+                                                C.c_void_p(d_offsets.data_ptr()), nb, self.block_size,
+                                                C.c_void_p(self.out.data_ptr()), self.out.numel(),
+                                                C.c_void_p(self.sizes.data_ptr()), C.c_void_p(self.status.data_ptr()),
+                                                C.c_void_p(self.summary.data_ptr()),
+                                                C.c_void_p(self.ws.data_ptr() + self.ws_off), self.ws_bytes,
+                                                _stream_ptr(torch))
+        _raise(st)
+        return self.out[: nb * self.block_size], self.sizes[:nb], self.status[:nb], self.summary
+
+
+# ---- synthetic workloads (BASELINE.json configs 2 and 5) ------------------------------------
+def gen_iid(nbytes, seed=0x5EED0001, first_byte=0, device="cuda:0", out=None):
+    torch = _torch()
+    t = out if out is not None else torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _raise(_lib.lib().redux_gen_iid_dev(C.c_void_p(t.data_ptr()), nbytes, first_byte, seed, _stream_ptr(torch)))
+    return t
+
+
+def gen_zipf(nbytes, seed=0x5EED0005, first_byte=0, device="cuda:0", out=None):
+    torch = _torch()
+    t = out if out is not None else torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _raise(_lib.lib().redux_gen_zipf_dev(C.c_void_p(t.data_ptr()), nbytes, first_byte, seed, _stream_ptr(torch)))
+    return t
+
+
+def zipf_thresholds():
+    p = _lib.lib().redux_zipf_thresholds()
+    return np.ctypeslib.as_array(p, shape=(256,)).copy()

@@ -1,0 +1,1017 @@
+// redux_hip.hip -- gfx950 kernels + the C ABI of include/redux_hip.h.
+//
+// Kernels (all hand-written for CDNA4, wave64):
+//   k_fill_rc        per-step reciprocal table 1/(257+i), biased up 4 ulp
+//   k_encode<..>     one lane = one block: tree in LDS, interval state in registers
+//   k_decode<..>     the inverse
+//   k_scan_sizes     sizes -> offsets (exclusive scan) + status summary
+//   k_compact        gather padded slots into the dense output
+//   k_gen_iid/zipf   synthetic workloads generated straight into HBM
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC redux_hip.hip -o libredux_hip.so
+#include "redux_coder.hpp"
+
+#include "../../include/redux_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace redux {
+
+// ======================================================================================
+// reciprocal table
+// ======================================================================================
+__global__ void k_fill_rc(double *rc, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double r = 1.0 / (double)(257u + i); // correctly rounded IEEE division
+        rc[i] = __longlong_as_double(__double_as_longlong(r) + 4);
+    }
+}
+
+// ======================================================================================
+// encode
+// ======================================================================================
+struct EncArgs {
+    const uint8_t *in;
+    uint64_t       in_len;
+    uint64_t       nblocks;
+    uint8_t       *slots;
+    uint64_t       slot_bytes;
+    uint32_t      *sizes;
+    int32_t       *status;
+    const double  *rc;
+    uint32_t       block_size;
+    uint32_t       slot_cap;  // usable bytes of a slot
+    uint32_t       nfreeze;   // freq_max - 257: number of updates before the freeze
+    uint32_t       code_bits;
+    uint32_t       aligned16; // in and block_size are 16-byte multiples
+};
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t w = __shfl_xor(v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t w = __shfl_xor(v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+template <bool U16, bool FIXUP>
+__global__ void __launch_bounds__(64) k_encode(EncArgs a)
+{
+    __shared__ uint32_t lds[Tree<U16>::kDwords];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
+    const bool     live = blk < a.nblocks;
+
+    for (uint32_t i = lane; i < Tree<U16>::kDwords / 4; i += 64)
+        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    Tree<U16> T;
+    T.init(lds, lane);
+
+    uint32_t len = 0;
+    uint64_t off = 0;
+    if (live) {
+        off                = blk * a.block_size;
+        const uint64_t rem = a.in_len - off;
+        len                = rem < a.block_size ? (uint32_t)rem : a.block_size;
+    }
+    const uint8_t *src = a.in + off;
+    uint8_t       *out = a.slots + (live ? blk : 0) * a.slot_bytes;
+    const uint32_t cap = live ? a.slot_cap : 0;
+
+    // Wave-uniform bounds (SGPRs): the lock-step loop covers [0, maxlen]; the fast path
+    // covers whole 16-byte chunks strictly below the shortest live block's last symbol.
+    const uint32_t minlen  = __builtin_amdgcn_readfirstlane(wave_min(live ? len : 0xFFFFFFFFu));
+    const uint32_t maxlen  = __builtin_amdgcn_readfirstlane(wave_max(live ? len : 0u));
+    const uint32_t sh      = 32 - a.code_bits;
+    const uint32_t nfreeze = a.nfreeze;
+
+    EncState S;
+    S.low = 0; S.high = 0xFFFFFFFFu; S.pend = 0; S.nb = 0; S.pos = 0; S.acc = 0; // codec.rs:28-36
+
+    uint32_t p        = 0;
+    uint32_t main_end = 0;
+    if (a.aligned16 && minlen != 0xFFFFFFFFu && minlen > 16)
+        main_end = (minlen - 1) & ~15u;
+
+    if (main_end) {
+        uint4 cur = *reinterpret_cast<const uint4 *>(src);
+        for (; p < main_end; p += 16) {
+            uint4 nxt = cur;
+            if (p + 16 < main_end)
+                nxt = *reinterpret_cast<const uint4 *>(src + p + 16);
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t s   = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                const uint32_t q   = p + i;
+                const uint32_t nup = q < nfreeze ? q : nfreeze; // updates so far (uniform)
+                const double   rc  = a.rc[nup];
+                uint32_t       e[8], lo, hi;
+                T.range(s, nup, e, lo, hi);
+                if (q < nfreeze) // adaptive_tree.rs:84: frozen once count == freq_max
+                    tree_update(T, s, e);
+                encode_symbol<FIXUP>(S, lo, hi, 257u + nup, rc, sh, false, out, cap);
+            }
+            cur = nxt;
+        }
+    }
+
+    // Tail: symbol by symbol with per-lane predicates (ragged lengths, the EOF symbol).
+    for (; p <= maxlen; p++) {
+        const uint32_t nup = p < nfreeze ? p : nfreeze;
+        const double   rc  = a.rc[nup];
+        const uint32_t c   = 257u + nup;
+        if (live && p < len) {
+            const uint32_t s = src[p];
+            uint32_t       e[8], lo, hi;
+            T.range(s, nup, e, lo, hi);
+            // The update of a block's last symbol is never observed (the EOF range is
+            // derived), and skipping it keeps every u16 node below 65536.
+            if (p < nfreeze && p + 1 != len)
+                tree_update(T, s, e);
+            encode_symbol<FIXUP>(S, lo, hi, c, rc, sh, false, out, cap);
+        } else if (live && p == len) {
+            // EOF symbol (codec.rs:108): cum(256) = count-1, cum(257) = count
+            encode_symbol<FIXUP>(S, c - 1, c, c, rc, sh, true, out, cap);
+            a.sizes[blk]  = S.pos;
+            a.status[blk] = S.pos > cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+        }
+    }
+}
+
+
+// ======================================================================================
+// decode
+// ======================================================================================
+struct DecArgs {
+    const uint8_t  *in;
+    const uint64_t *in_offsets; // nblocks + 1
+    uint64_t        nblocks;
+    uint8_t        *out;        // block b at out + b*block_size
+    uint32_t       *out_sizes;
+    int32_t        *status;
+    const double   *rc;
+    uint32_t        block_size;
+    uint32_t        nfreeze;
+    uint32_t        code_bits;
+    uint32_t        aligned4;   // out and block_size are 4-byte multiples
+};
+
+// BitReader (bitio/mod.rs:78-120) as a 64-bit look-ahead register: the `cnt` not yet
+// consumed bits sit in the TOP of `bits`; refills are whole aligned dwords, big-endian
+// (MSB-first stream).  Reads past the stream's last dword yield zeros; running past the end
+// is detected by the consumed-bit count, exactly where read_bits would return Err(Eof).
+struct BitIn {
+    uint64_t        bits;
+    uint32_t        cnt;
+    const uint32_t *rp, *end;
+
+    __device__ __forceinline__ void refill()
+    {
+        if (cnt <= 32) {
+            const uint32_t w = rp < end ? __builtin_bswap32(*rp) : 0u;
+            rp++;
+            bits |= (uint64_t)w << (32 - cnt);
+            cnt += 32;
+        }
+    }
+    __device__ __forceinline__ void init(const uint8_t *sp, uint64_t size)
+    {
+        const uintptr_t a = (uintptr_t)sp & ~(uintptr_t)3;
+        const uint32_t  skip = (uint32_t)((uintptr_t)sp & 3) * 8;
+        rp   = reinterpret_cast<const uint32_t *>(a);
+        end  = reinterpret_cast<const uint32_t *>(((uintptr_t)sp + size + 3) & ~(uintptr_t)3);
+        bits = 0;
+        cnt  = 0;
+        refill();
+        bits <<= skip;
+        cnt -= skip;
+        refill();
+    }
+    // next n (<= 32) bits, MSB first
+    __device__ __forceinline__ uint32_t take(uint32_t n)
+    {
+        const uint32_t v = (uint32_t)((bits >> 1) >> (63 - n));
+        bits <<= n;
+        cnt -= n;
+        refill();
+        return v;
+    }
+};
+
+template <bool U16, bool FIXUP>
+__global__ void __launch_bounds__(64) k_decode(DecArgs a)
+{
+    __shared__ uint32_t lds[Tree<U16>::kDwords];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
+    const bool     live = blk < a.nblocks;
+
+    for (uint32_t i = lane; i < Tree<U16>::kDwords / 4; i += 64)
+        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    Tree<U16> T;
+    T.init(lds, lane);
+
+    const uint32_t cb = a.code_bits, sh = 32 - cb;
+    uint64_t       size = 0;
+    const uint8_t *sp   = a.in;
+    if (live) {
+        const uint64_t o0 = a.in_offsets[blk];
+        size              = a.in_offsets[blk + 1] - o0;
+        sp                = a.in + o0;
+    }
+    const uint64_t stream_bits = size * 8;
+    uint8_t       *dst         = a.out + (live ? blk : 0) * (uint64_t)a.block_size;
+    const uint32_t capn        = a.block_size;
+
+    BitIn B;
+    B.init(sp, live ? size : 0);
+    // decompress_symbol's first call pulls code_bits bits into `pending` (codec.rs:124-127)
+    // decompress_symbol's first call pulls code_bits bits into `pending` (codec.rs:124-127).
+    // W holds that value left-aligned (value << sh), like low/high.
+    uint32_t W = B.take(cb) << sh;
+    uint64_t consumed = cb;
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    int32_t  st   = REDUX_OK;
+    bool     done = !live;
+    if (live && consumed > stream_bits) { // stream shorter than code_bits: Err(Eof) at once
+        st   = REDUX_EOF;
+        done = true;
+    }
+    uint32_t n_out = 0;
+    uint32_t obuf  = 0;
+
+    for (uint32_t p = 0;; p++) {
+        if (__builtin_amdgcn_readfirstlane(__ballot(!done) == 0))
+            break;
+        const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
+        const double   rc  = a.rc[nup];
+        const uint32_t c   = 257u + nup;
+        if (!done) {
+            // value = ((pending - low + 1) * count - 1) / range      (codec.rs:129-131)
+            const uint32_t R1  = (high - low) >> sh;
+            const uint32_t Vd  = (W - low) >> sh;
+            const uint64_t num = ((uint64_t)Vd + 1) * c - 1;
+            const double   xd  = (double)R1 + 1.0;
+            uint32_t       v   = (uint32_t)((double)num / xd);
+            {
+                const int64_t r = (int64_t)(num - ((uint64_t)v * R1 + v));
+                if (r < 0)
+                    v--;
+                else if ((uint64_t)r > (uint64_t)R1)
+                    v++;
+            }
+            // get_symbol (adaptive_tree.rs:115-136)
+            uint32_t lo, hi;
+            bool     is_eof = false;
+            uint32_t s      = 0;
+            if (v >= c - 1) { // first probe: tree[256] = 256 + #updates = count - 1
+                is_eof = true;
+                lo     = c - 1;
+                hi     = c;
+            } else {
+                uint32_t x[8], e[8];
+                uint32_t i = 0, rem = v;
+#pragma unroll
+                for (int b = 7; b >= 0; b--) {
+                    e[b] = i | (1u << b);
+                    x[b] = T.node(e[b]);
+                    const uint32_t tv = (1u << b) + x[b];
+                    if (rem >= tv) {
+                        i = e[b];
+                        rem -= tv;
+                    }
+                }
+                s  = i;
+                lo = v - rem;
+                const uint32_t m = s + 1;
+                uint32_t       hs = m;
+#pragma unroll
+                for (int b = 0; b < 8; b++)
+                    hs += ((m >> b) & 1u) ? x[b] : 0u;
+                hi = hs + (s == 255u ? nup : 0u);
+                if (p < a.nfreeze) {
+#pragma unroll
+                    for (int b = 0; b < 8; b++)
+                        if (!((s >> b) & 1u))
+                            T.bump(e[b]);
+                }
+            }
+            if (is_eof) { // codec.rs:136-138: returns before any renormalisation
+                done = true;
+            } else if (p >= capn) {
+                st   = REDUX_OUTPUT_TOO_SMALL;
+                done = true;
+            } else {
+                const double   Y     = __builtin_fma((double)R1, rc, rc);
+                const uint32_t nlow  = low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
+                const uint32_t nhigh = low + (scale_div<FIXUP>(R1, Y, hi, c) << sh) - 1u;
+                const uint32_t xx    = nlow ^ nhigh;
+                const uint32_t k     = xx ? (uint32_t)__builtin_clz(xx) : 32u;
+                const uint32_t low2  = (uint32_t)((uint64_t)nlow << k);
+                const uint32_t ih2   = (uint32_t)((uint64_t)(~nhigh) << k);
+                const uint32_t t     = (low2 & ih2) << 1;
+                const uint32_t j     = (uint32_t)__builtin_clz(~t);
+                low                  = (low2 << j) & 0x7FFFFFFFu;
+                high                 = ~((ih2 << j) & 0x7FFFFFFFu);
+                const uint32_t n     = k + j; // bits pulled by get_bit (codec.rs:157)
+                consumed += n;
+                if (consumed > stream_bits) { // read_bits would hit Err(Eof) (bitio/mod.rs:107)
+                    st   = REDUX_EOF;
+                    done = true;
+                } else {
+                    // k E1/E2 steps shift the value left (codec.rs:143-146 + :155-157); each of
+                    // the j E3 steps then drops the bit just below the top one (:147-151).  On
+                    // the 64-bit image [value | n new bits] that is: shift by k, remember the top
+                    // bit, shift by j more, put the remembered top bit back.
+                    const uint32_t nb   = B.take(n);
+                    const uint64_t comb = ((uint64_t)W << 32) | ((uint64_t)nb << (32 + sh - n));
+                    const uint64_t c1   = comb << k;
+                    const uint64_t c2   = c1 << j;
+                    W = (((uint32_t)(c2 >> 32) & 0x7FFFFFFFu) | ((uint32_t)(c1 >> 32) & 0x80000000u)) &
+                        (0xFFFFFFFFu << sh);
+                    // emit the symbol (write_bits(symbol, 8), codec.rs:171)
+                    if (a.aligned4) {
+                        obuf |= s << (8 * (p & 3));
+                        if ((p & 3) == 3) {
+                            *reinterpret_cast<uint32_t *>(dst + (p & ~3u)) = obuf;
+                            obuf = 0;
+                        }
+                    } else {
+                        dst[p] = (uint8_t)s;
+                    }
+                    n_out = p + 1;
+                }
+            }
+        }
+    }
+    if (live) {
+        if (a.aligned4)
+            for (uint32_t i = n_out & ~3u; i < n_out; i++)
+                dst[i] = (uint8_t)(obuf >> (8 * (i & 3)));
+        a.out_sizes[blk] = n_out;
+        a.status[blk]    = st;
+    }
+}
+
+__global__ void k_summarize(const int32_t *status, uint64_t nblocks, int32_t *summary)
+{
+    uint32_t bad = 0;
+    uint64_t first = ~0ull;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += (uint64_t)gridDim.x * blockDim.x)
+        if (status[b] != REDUX_OK) {
+            bad++;
+            if (first == ~0ull)
+                first = b;
+        }
+    if (bad) {
+        atomicAdd(&summary[1], (int32_t)bad);
+        atomicCAS(&summary[0], REDUX_OK, status[first]);
+    }
+}
+
+// ======================================================================================
+// sizes -> offsets, status summary
+// ======================================================================================
+struct ScanArgs {
+    const uint32_t *sizes;
+    const int32_t  *status;
+    uint64_t       *offsets; // nblocks + 1
+    int32_t        *summary; // may be null: [first bad status, #bad]
+    uint64_t        nblocks;
+};
+
+__global__ void __launch_bounds__(1024) k_scan_sizes(ScanArgs a)
+{
+    __shared__ uint64_t part[1024];
+    __shared__ uint32_t bad_cnt;
+    __shared__ uint64_t bad_first; // (index << 8) | status, minimised
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        bad_cnt   = 0;
+        bad_first = ~0ull;
+    }
+    const uint64_t per = (a.nblocks + 1023) / 1024;
+    const uint64_t b0  = per * tid < a.nblocks ? per * tid : a.nblocks;
+    const uint64_t b1  = b0 + per < a.nblocks ? b0 + per : a.nblocks;
+    uint64_t       sum = 0;
+    uint32_t       nb  = 0;
+    uint64_t       fb  = ~0ull;
+    for (uint64_t b = b0; b < b1; b++) {
+        sum += a.sizes[b];
+        const int32_t st = a.status[b];
+        if (st != REDUX_OK) {
+            nb++;
+            if (fb == ~0ull)
+                fb = (b << 8) | (uint32_t)st;
+        }
+    }
+    part[tid] = sum;
+    __syncthreads();
+    if (nb) {
+        atomicAdd(&bad_cnt, nb);
+        atomicMin((unsigned long long *)&bad_first, (unsigned long long)fb);
+    }
+    // Hillis-Steele inclusive scan over the 1024 partials
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint64_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint64_t run = tid ? part[tid - 1] : 0;
+    for (uint64_t b = b0; b < b1; b++) {
+        a.offsets[b] = run;
+        run += a.sizes[b];
+    }
+    if (tid == 1023)
+        a.offsets[a.nblocks] = part[1023];
+    if (tid == 0 && a.summary) {
+        a.summary[0] = bad_cnt ? (int32_t)(bad_first & 0xFF) : REDUX_OK;
+        a.summary[1] = (int32_t)bad_cnt;
+    }
+}
+
+// ======================================================================================
+// compaction: slot b [0, size_b) -> out + offsets[b]
+// ======================================================================================
+struct CompactArgs {
+    const uint8_t  *slots;
+    uint64_t        slot_bytes;
+    const uint64_t *offsets;
+    uint8_t        *out;
+    uint64_t        out_cap;
+    int32_t        *status;
+    int32_t        *summary;
+    uint64_t        nblocks;
+};
+
+__global__ void __launch_bounds__(256) k_compact(CompactArgs a)
+{
+    const uint64_t b = blockIdx.x;
+    if (b >= a.nblocks)
+        return;
+    const uint64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
+    const uint32_t tid = threadIdx.x;
+    if (o1 > a.out_cap) { // the dense buffer is too small for this block: report, never write
+        if (tid == 0) {
+            if (a.status[b] == REDUX_OK)
+                a.status[b] = REDUX_OUTPUT_TOO_SMALL;
+            if (a.summary) {
+                atomicCAS(&a.summary[0], REDUX_OK, REDUX_OUTPUT_TOO_SMALL);
+                atomicAdd(&a.summary[1], 1);
+            }
+        }
+        return;
+    }
+    const uint32_t n   = (uint32_t)(o1 - o0);
+    const uint8_t *src = a.slots + b * a.slot_bytes; // 16-byte aligned
+    uint8_t       *dst = a.out + o0;
+
+    // head: bytes up to the first 16-byte boundary of dst
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (head > n)
+        head = n;
+    if (tid < head)
+        dst[tid] = src[tid];
+    // body: 16-byte dst chunks; the source is misaligned by the uniform amount `head`
+    const uint32_t nchunks = (n - head) >> 4;
+    const uint32_t dq = head >> 2, r = head & 3;
+    const uint4   *s16 = reinterpret_cast<const uint4 *>(src);
+    uint4         *d16 = reinterpret_cast<uint4 *>(dst + head);
+    for (uint32_t i = tid; i < nchunks; i += 256) {
+        const uint4    A = s16[i], B = s16[i + 1]; // slot padding keeps i+1 inside the slot
+        const uint32_t d[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
+        uint32_t       v[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            v[k] = dq == 0 ? d[k] : dq == 1 ? d[k + 1] : dq == 2 ? d[k + 2] : d[k + 3];
+        uint4 o;
+        o.x = __builtin_amdgcn_alignbyte(v[1], v[0], r);
+        o.y = __builtin_amdgcn_alignbyte(v[2], v[1], r);
+        o.z = __builtin_amdgcn_alignbyte(v[3], v[2], r);
+        o.w = __builtin_amdgcn_alignbyte(v[4], v[3], r);
+        d16[i] = o;
+    }
+    // tail
+    const uint32_t done = head + (nchunks << 4);
+    if (tid < n - done)
+        dst[done + tid] = src[done + tid];
+}
+
+// ======================================================================================
+// synthetic workloads
+// ======================================================================================
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z          = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__constant__ uint32_t c_zipf[256] = {
+#include "zipf_table.inc"
+};
+static const uint32_t h_zipf[256] = {
+#include "zipf_table.inc"
+};
+
+// byte j of the stream = byte (j mod 8) of splitmix64(seed + j/8); first_byte must be a
+// multiple of 8 for the fast path, any value otherwise.
+__global__ void k_gen_iid(uint8_t *out, uint64_t len, uint64_t first, uint64_t seed)
+{
+    const uint64_t nwords = (len + 7) / 8 + 1;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords;
+         w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t j0 = ((first >> 3) + w) << 3; // stream byte index of this word
+        const uint64_t v  = splitmix64(seed + (j0 >> 3));
+        if (j0 >= first && j0 + 8 <= first + len && (((uintptr_t)(out + (j0 - first))) & 7) == 0) {
+            *reinterpret_cast<uint64_t *>(out + (j0 - first)) = v;
+        } else {
+            for (int k = 0; k < 8; k++) {
+                const uint64_t j = j0 + k;
+                if (j >= first && j < first + len)
+                    out[j - first] = (uint8_t)(v >> (8 * k));
+            }
+        }
+    }
+}
+
+__global__ void k_gen_zipf(uint8_t *out, uint64_t len, uint64_t first, uint64_t seed)
+{
+    const uint64_t ngroups = (len + 3) / 4;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
+         g += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t packed = 0;
+        for (int k = 0; k < 4; k++) {
+            const uint64_t j = g * 4 + k;
+            const uint32_t u = (uint32_t)(splitmix64(seed + first + j) >> 32);
+            // smallest r-1 with u <= thresholds[r-1]: 8-step binary search
+            uint32_t lo = 0, hi = 255;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (u <= c_zipf[mid])
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            packed |= lo << (8 * k);
+        }
+        if (g * 4 + 4 <= len && (((uintptr_t)out) & 3) == 0) {
+            reinterpret_cast<uint32_t *>(out)[g] = packed;
+        } else {
+            for (int k = 0; k < 4; k++)
+                if (g * 4 + k < len)
+                    out[g * 4 + k] = (uint8_t)(packed >> (8 * k));
+        }
+    }
+}
+
+// ======================================================================================
+// host side of the ABI
+// ======================================================================================
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+struct Geometry {
+    uint64_t nblocks;
+    uint64_t slot_bytes; // stride between slots (16-byte multiple, >= cap + 32)
+    uint32_t slot_cap;   // usable bytes
+    uint32_t rc_n;       // reciprocal table entries
+    uint32_t nfreeze;
+    bool     u16, fixup;
+    // workspace layout (encode)
+    uint64_t off_rc, off_sizes, off_slots, total;
+};
+
+static int check_params(const redux_params *p)
+{
+    if (!p)
+        return REDUX_INVALID_INPUT;
+    const int st = redux_params_check(p->symbol_bits, p->freq_bits, p->code_bits);
+    if (st != REDUX_OK)
+        return st;
+    if (p->symbol_bits != 8 || p->code_bits > 32)
+        return REDUX_UNSUPPORTED;
+    return REDUX_OK;
+}
+
+static uint64_t slot_cap_for(const redux_params *p, uint32_t block_size)
+{
+    // Worst case of one block's stream.  While the model never freezes inside a block the
+    // adaptive code length is <= 8 bits/symbol + O(256 log N) and the integer truncation of
+    // codec.rs:59-60 loses < 1 bit/symbol: 9 bits/symbol.  Once frozen (count == freq_max) a
+    // symbol of frequency 1 costs up to freq_bits + 1 bits.
+    const uint64_t freq_max = (1ull << p->freq_bits) - 1;
+    const uint64_t n        = block_size;
+    const bool     freezes  = 257ull + n > freq_max;
+    const uint64_t bits     = freezes ? n * (p->freq_bits + 2) : n * 9;
+    return bits / 8 + 1024;
+}
+
+static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_size)
+{
+    Geometry g;
+    memset(&g, 0, sizeof g);
+    g.nblocks = in_len == 0 ? 1 : (in_len + block_size - 1) / block_size;
+    const uint64_t cap = slot_cap_for(p, block_size);
+    g.slot_cap   = cap > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)cap;
+    g.slot_bytes = align_up((uint64_t)g.slot_cap + 32, 16);
+    const uint64_t freq_max = (1ull << p->freq_bits) - 1;
+    g.nfreeze = (uint32_t)(freq_max - 257);
+    const uint64_t maxlen = in_len < block_size ? in_len : block_size;
+    g.rc_n  = (uint32_t)((maxlen < g.nfreeze ? maxlen : g.nfreeze) + 1);
+    g.u16   = block_size <= 65536;
+    g.fixup = (257ull + (uint64_t)(g.rc_n - 1)) >= (1ull << 17);
+    g.off_rc    = 0;
+    g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
+    g.off_slots = align_up(g.off_sizes + g.nblocks * 4, 256);
+    g.total     = g.off_slots + g.nblocks * g.slot_bytes;
+    return g;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            fprintf(stderr, "redux_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_),       \
+                    __FILE__, __LINE__);                                                               \
+            return REDUX_IO_ERROR;                                                                     \
+        }                                                                                              \
+    } while (0)
+
+} // namespace redux
+
+using namespace redux;
+
+extern "C" {
+
+const char *redux_version(void) { return "redux_hip 0.1.0 gfx950"; }
+
+int redux_params_check(uint32_t symbol, uint32_t frequency, uint32_t code) /* model/mod.rs:64 */
+{
+    if (symbol < 1 || frequency < symbol + 2 || code < frequency + 2 || 64 < code + frequency)
+        return REDUX_INVALID_INPUT;
+    return REDUX_OK;
+}
+
+int redux_device_supports(const redux_params *p) { return check_params(p); }
+
+uint64_t redux_block_count(uint64_t in_len, uint32_t block_size)
+{
+    if (block_size == 0)
+        return 0;
+    return in_len == 0 ? 1 : (in_len + block_size - 1) / block_size;
+}
+
+uint64_t redux_encode_slot_bytes(const redux_params *p, uint32_t block_size)
+{
+    if (check_params(p) != REDUX_OK || block_size == 0)
+        return 0;
+    return geometry(p, block_size, block_size).slot_cap;
+}
+
+uint64_t redux_encode_bound(const redux_params *p, uint64_t in_len, uint32_t block_size)
+{
+    if (check_params(p) != REDUX_OK || block_size == 0)
+        return 0;
+    const Geometry g = geometry(p, in_len, block_size);
+    return g.nblocks * (uint64_t)g.slot_cap;
+}
+
+uint64_t redux_encode_workspace_bytes(const redux_params *p, uint64_t in_len, uint32_t block_size)
+{
+    if (check_params(p) != REDUX_OK || block_size == 0)
+        return 0;
+    return geometry(p, in_len, block_size).total;
+}
+
+int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size,
+                           void *d_block_status, void *d_workspace, uint64_t workspace_bytes, void *stream)
+{
+    int st = check_params(p);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0 || !d_workspace || !d_block_status || (in_len && !d_in))
+        return REDUX_INVALID_INPUT;
+    const Geometry g = geometry(p, in_len, block_size);
+    if (workspace_bytes < g.total)
+        return REDUX_OUTPUT_TOO_SMALL;
+    if (((uintptr_t)d_workspace) & 255)
+        return REDUX_INVALID_INPUT;
+    hipStream_t s  = (hipStream_t)stream;
+    uint8_t    *ws = (uint8_t *)d_workspace;
+
+    k_fill_rc<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)(ws + g.off_rc), g.rc_n);
+
+    EncArgs a;
+    a.in         = (const uint8_t *)d_in;
+    a.in_len     = in_len;
+    a.nblocks    = g.nblocks;
+    a.slots      = ws + g.off_slots;
+    a.slot_bytes = g.slot_bytes;
+    a.sizes      = (uint32_t *)(ws + g.off_sizes);
+    a.status     = (int32_t *)d_block_status;
+    a.rc         = (const double *)(ws + g.off_rc);
+    a.block_size = block_size;
+    a.slot_cap   = g.slot_cap;
+    a.nfreeze    = g.nfreeze;
+    a.code_bits  = p->code_bits;
+    a.aligned16  = ((((uintptr_t)d_in) & 15) == 0 && (block_size & 15) == 0) ? 1 : 0;
+    const uint32_t grid = (uint32_t)((g.nblocks + 63) / 64);
+    if (g.u16 && !g.fixup)
+        k_encode<true, false><<<grid, 64, 0, s>>>(a);
+    else if (g.u16)
+        k_encode<true, true><<<grid, 64, 0, s>>>(a);
+    else
+        k_encode<false, true><<<grid, 64, 0, s>>>(a);
+    HIP_TRY(hipGetLastError());
+    return REDUX_OK;
+}
+
+int redux_compact_slots_dev(const redux_params *p, uint64_t in_len, uint32_t block_size, void *d_out,
+                            uint64_t out_cap, void *d_out_offsets, void *d_block_status, void *d_summary,
+                            void *d_workspace, uint64_t workspace_bytes, void *stream)
+{
+    int st = check_params(p);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0 || !d_workspace || !d_block_status || !d_out_offsets || !d_out)
+        return REDUX_INVALID_INPUT;
+    const Geometry g = geometry(p, in_len, block_size);
+    if (workspace_bytes < g.total)
+        return REDUX_OUTPUT_TOO_SMALL;
+    hipStream_t s  = (hipStream_t)stream;
+    uint8_t    *ws = (uint8_t *)d_workspace;
+
+    ScanArgs sa;
+    sa.sizes   = (const uint32_t *)(ws + g.off_sizes);
+    sa.status  = (const int32_t *)d_block_status;
+    sa.offsets = (uint64_t *)d_out_offsets;
+    sa.summary = (int32_t *)d_summary;
+    sa.nblocks = g.nblocks;
+    k_scan_sizes<<<1, 1024, 0, s>>>(sa);
+
+    CompactArgs ca;
+    ca.slots      = ws + g.off_slots;
+    ca.slot_bytes = g.slot_bytes;
+    ca.offsets    = (const uint64_t *)d_out_offsets;
+    ca.out        = (uint8_t *)d_out;
+    ca.out_cap    = out_cap;
+    ca.status     = (int32_t *)d_block_status;
+    ca.summary    = (int32_t *)d_summary;
+    ca.nblocks    = g.nblocks;
+    k_compact<<<(uint32_t)g.nblocks, 256, 0, s>>>(ca);
+    HIP_TRY(hipGetLastError());
+    return REDUX_OK;
+}
+
+int redux_encode_blocks_dev(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size,
+                            void *d_out, uint64_t out_cap, void *d_out_offsets, void *d_block_status,
+                            void *d_summary, void *d_workspace, uint64_t workspace_bytes, void *stream)
+{
+    int st = redux_encode_slots_dev(p, d_in, in_len, block_size, d_block_status, d_workspace, workspace_bytes, stream);
+    if (st != REDUX_OK)
+        return st;
+    return redux_compact_slots_dev(p, in_len, block_size, d_out, out_cap, d_out_offsets, d_block_status, d_summary,
+                                   d_workspace, workspace_bytes, stream);
+}
+
+int redux_encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_len, uint32_t block_size,
+                        uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
+{
+    int st = check_params(p);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0 || !out || !out_offsets || (in_len && !in))
+        return REDUX_INVALID_INPUT;
+    const Geometry g = geometry(p, in_len, block_size);
+    uint8_t *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr;
+    uint64_t *d_off = nullptr;
+    int32_t  *d_st = nullptr, *d_sum = nullptr;
+    int       rc = REDUX_OK;
+    int32_t   summary[2] = {0, 0};
+#define TRY_GOTO(expr)                                                                                 \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            fprintf(stderr, "redux_hip: %s failed: %s\n", #expr, hipGetErrorString(e_));              \
+            rc = REDUX_IO_ERROR;                                                                       \
+            goto done;                                                                                 \
+        }                                                                                              \
+    } while (0)
+    TRY_GOTO(hipMalloc((void **)&d_in, in_len ? in_len : 16));
+    TRY_GOTO(hipMalloc((void **)&d_out, out_cap ? out_cap : 16));
+    TRY_GOTO(hipMalloc((void **)&d_ws, g.total));
+    TRY_GOTO(hipMalloc((void **)&d_off, (g.nblocks + 1) * 8));
+    TRY_GOTO(hipMalloc((void **)&d_st, g.nblocks * 4));
+    TRY_GOTO(hipMalloc((void **)&d_sum, 8));
+    if (in_len)
+        TRY_GOTO(hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice));
+    TRY_GOTO(hipMemset(d_sum, 0, 8));
+    rc = redux_encode_blocks_dev(p, d_in, in_len, block_size, d_out, out_cap, d_off, d_st, d_sum, d_ws, g.total, nullptr);
+    if (rc != REDUX_OK)
+        goto done;
+    TRY_GOTO(hipDeviceSynchronize());
+    TRY_GOTO(hipMemcpy(out_offsets, d_off, (g.nblocks + 1) * 8, hipMemcpyDeviceToHost));
+    TRY_GOTO(hipMemcpy(summary, d_sum, 8, hipMemcpyDeviceToHost));
+    if (block_status)
+        TRY_GOTO(hipMemcpy(block_status, d_st, g.nblocks * 4, hipMemcpyDeviceToHost));
+    if (out_offsets[g.nblocks] <= out_cap)
+        TRY_GOTO(hipMemcpy(out, d_out, out_offsets[g.nblocks], hipMemcpyDeviceToHost));
+    rc = summary[0];
+done:
+    hipFree(d_in); hipFree(d_out); hipFree(d_ws); hipFree(d_off); hipFree(d_st); hipFree(d_sum);
+    return rc;
+#undef TRY_GOTO
+}
+
+int redux_compress(const redux_params *p, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
+                   uint64_t *bytes_in, uint64_t *bytes_out) /* src/lib.rs:102-109 */
+{
+    if (in_len > 0xFFFFFF00ull)
+        return REDUX_UNSUPPORTED;
+    uint64_t  offs[2] = {0, 0};
+    int32_t   st      = 0;
+    const int rc = redux_encode_blocks(p, in, in_len, in_len ? (uint32_t)in_len : 1u, out, out_cap, offs, &st);
+    if (rc == REDUX_OK) {
+        if (bytes_in)
+            *bytes_in = in_len;
+        if (bytes_out)
+            *bytes_out = offs[1];
+    }
+    return rc;
+}
+
+uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, uint32_t block_size)
+{
+    (void)nblocks;
+    if (check_params(p) != REDUX_OK || block_size == 0)
+        return 0;
+    const Geometry g = geometry(p, block_size, block_size);
+    return align_up((uint64_t)g.rc_n * 8, 256);
+}
+
+int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void *d_in_offsets, uint64_t nblocks,
+                            uint32_t block_size, void *d_out, uint64_t out_cap, void *d_out_sizes,
+                            void *d_block_status, void *d_summary, void *d_workspace, uint64_t workspace_bytes,
+                            void *stream)
+{
+    int st = check_params(p);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0 || !d_in_offsets || !d_out_sizes || !d_block_status || !d_workspace)
+        return REDUX_INVALID_INPUT;
+    if (nblocks == 0)
+        return REDUX_OK;
+    if (out_cap < nblocks * (uint64_t)block_size)
+        return REDUX_OUTPUT_TOO_SMALL;
+    const Geometry g = geometry(p, block_size, block_size);
+    if (workspace_bytes < align_up((uint64_t)g.rc_n * 8, 256))
+        return REDUX_OUTPUT_TOO_SMALL;
+    hipStream_t s = (hipStream_t)stream;
+    k_fill_rc<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)d_workspace, g.rc_n);
+    DecArgs a;
+    a.in         = (const uint8_t *)d_in;
+    a.in_offsets = (const uint64_t *)d_in_offsets;
+    a.nblocks    = nblocks;
+    a.out        = (uint8_t *)d_out;
+    a.out_sizes  = (uint32_t *)d_out_sizes;
+    a.status     = (int32_t *)d_block_status;
+    a.rc         = (const double *)d_workspace;
+    a.block_size = block_size;
+    a.nfreeze    = g.nfreeze;
+    a.code_bits  = p->code_bits;
+    a.aligned4   = ((((uintptr_t)d_out) & 3) == 0 && (block_size & 3) == 0) ? 1 : 0;
+    const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
+    if (g.u16 && !g.fixup)
+        k_decode<true, false><<<grid, 64, 0, s>>>(a);
+    else if (g.u16)
+        k_decode<true, true><<<grid, 64, 0, s>>>(a);
+    else
+        k_decode<false, true><<<grid, 64, 0, s>>>(a);
+    if (d_summary)
+        k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
+    HIP_TRY(hipGetLastError());
+    return REDUX_OK;
+}
+
+int redux_decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
+                        uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes,
+                        int32_t *block_status)
+{
+    int st = check_params(p);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0 || !in_offsets || !out_sizes || (nblocks && !out))
+        return REDUX_INVALID_INPUT;
+    if (nblocks == 0)
+        return REDUX_OK;
+    if (out_cap < nblocks * (uint64_t)block_size)
+        return REDUX_OUTPUT_TOO_SMALL;
+    const uint64_t in_len = in_offsets[nblocks];
+    const uint64_t wsb    = redux_decode_workspace_bytes(p, nblocks, block_size);
+    uint8_t  *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr;
+    uint64_t *d_off = nullptr;
+    uint32_t *d_sz = nullptr;
+    int32_t  *d_st = nullptr, *d_sum = nullptr;
+    int       rc = REDUX_OK;
+    int32_t   summary[2] = {0, 0};
+#define TRY_GOTO(expr)                                                                                 \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            fprintf(stderr, "redux_hip: %s failed: %s\n", #expr, hipGetErrorString(e_));              \
+            rc = REDUX_IO_ERROR;                                                                       \
+            goto done;                                                                                 \
+        }                                                                                              \
+    } while (0)
+    TRY_GOTO(hipMalloc((void **)&d_in, in_len + 16));
+    TRY_GOTO(hipMalloc((void **)&d_out, nblocks * (uint64_t)block_size));
+    TRY_GOTO(hipMalloc((void **)&d_ws, wsb));
+    TRY_GOTO(hipMalloc((void **)&d_off, (nblocks + 1) * 8));
+    TRY_GOTO(hipMalloc((void **)&d_sz, nblocks * 4));
+    TRY_GOTO(hipMalloc((void **)&d_st, nblocks * 4));
+    TRY_GOTO(hipMalloc((void **)&d_sum, 8));
+    if (in_len)
+        TRY_GOTO(hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice));
+    TRY_GOTO(hipMemcpy(d_off, in_offsets, (nblocks + 1) * 8, hipMemcpyHostToDevice));
+    TRY_GOTO(hipMemset(d_sum, 0, 8));
+    rc = redux_decode_blocks_dev(p, d_in, d_off, nblocks, block_size, d_out, nblocks * (uint64_t)block_size, d_sz, d_st,
+                                 d_sum, d_ws, wsb, nullptr);
+    if (rc != REDUX_OK)
+        goto done;
+    TRY_GOTO(hipDeviceSynchronize());
+    TRY_GOTO(hipMemcpy(out_sizes, d_sz, nblocks * 4, hipMemcpyDeviceToHost));
+    TRY_GOTO(hipMemcpy(summary, d_sum, 8, hipMemcpyDeviceToHost));
+    if (block_status)
+        TRY_GOTO(hipMemcpy(block_status, d_st, nblocks * 4, hipMemcpyDeviceToHost));
+    TRY_GOTO(hipMemcpy(out, d_out, nblocks * (uint64_t)block_size, hipMemcpyDeviceToHost));
+    rc = summary[0];
+done:
+    hipFree(d_in); hipFree(d_out); hipFree(d_ws); hipFree(d_off); hipFree(d_sz); hipFree(d_st); hipFree(d_sum);
+    return rc;
+#undef TRY_GOTO
+}
+
+int redux_decompress(const redux_params *p, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
+                     uint64_t *bytes_in, uint64_t *bytes_out) /* src/lib.rs:113-120 */
+{
+    if (out_cap == 0 || out_cap > 0xFFFFFF00ull)
+        out_cap = out_cap ? 0xFFFFFF00ull : 1;
+    uint64_t  offs[2] = {0, in_len};
+    uint32_t  sz      = 0;
+    int32_t   st      = 0;
+    const int rc = redux_decode_blocks(p, in, offs, 1, (uint32_t)out_cap, out, out_cap, &sz, &st);
+    if (rc == REDUX_OK) {
+        if (bytes_out)
+            *bytes_out = sz;
+        // The decoder consumes exactly the bits the encoder wrote: the
+        // reference's reader count is the stream length without trailing junk; bytes_in is
+        // reported as the number of bytes holding consumed bits.
+        if (bytes_in)
+            *bytes_in = in_len;
+    }
+    return rc;
+}
+
+int redux_gen_iid_dev(void *d_out, uint64_t len, uint64_t first_byte, uint64_t seed, void *stream)
+{
+    if (len == 0)
+        return REDUX_OK;
+    k_gen_iid<<<2048, 256, 0, (hipStream_t)stream>>>((uint8_t *)d_out, len, first_byte, seed);
+    HIP_TRY(hipGetLastError());
+    return REDUX_OK;
+}
+
+int redux_gen_zipf_dev(void *d_out, uint64_t len, uint64_t first_byte, uint64_t seed, void *stream)
+{
+    if (len == 0)
+        return REDUX_OK;
+    k_gen_zipf<<<2048, 256, 0, (hipStream_t)stream>>>((uint8_t *)d_out, len, first_byte, seed);
+    HIP_TRY(hipGetLastError());
+    return REDUX_OK;
+}
+
+const uint32_t *redux_zipf_thresholds(void) { return h_zipf; }
+
+} // extern "C"

@@ -1,0 +1,106 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol
+include/redux_hip.h declares, and its host-only entry points (validation, geometry) behave
+like the reference's Parameters::new (src/model/mod.rs:64).  No compute call is made."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import cbind as ox
+from redux_amd import _lib, api
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "redux_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(redux_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = declared_functions()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(L, n), f"libredux_hip.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"ctypes signature missing for {n}"
+    assert b"gfx950" in L.redux_version()
+
+
+def test_params_check_matches_reference_rule():
+    L = _lib.lib()
+    for s in range(0, 14):
+        for f in range(0, 40, 1):
+            for c in (f, f + 1, f + 2, f + 3, 32, 33, 64 - f, 65 - f):
+                if c < 0:
+                    continue
+                want = ox.lib().ox_params_new(s, f, c, C.byref(ox.Params()))
+                got = L.redux_params_check(s, f, c)
+                assert (got == 0) == (want == 0), (s, f, c)
+                assert got in (_lib.OK, _lib.INVALID_INPUT)
+
+
+def test_device_supports():
+    L = _lib.lib()
+    assert L.redux_device_supports(C.byref(_lib.Params(8, 30, 32))) == _lib.OK
+    assert L.redux_device_supports(C.byref(_lib.Params(8, 14, 16))) == _lib.OK
+    assert L.redux_device_supports(C.byref(_lib.Params(4, 10, 16))) == _lib.UNSUPPORTED
+    assert L.redux_device_supports(C.byref(_lib.Params(12, 14, 16))) == _lib.UNSUPPORTED
+    assert L.redux_device_supports(C.byref(_lib.Params(8, 24, 40))) == _lib.UNSUPPORTED
+    assert L.redux_device_supports(C.byref(_lib.Params(8, 9, 16))) == _lib.INVALID_INPUT
+
+
+def test_geometry():
+    L = _lib.lib()
+    assert L.redux_block_count(0, 65536) == 1
+    assert L.redux_block_count(1, 65536) == 1
+    assert L.redux_block_count(65536, 65536) == 1
+    assert L.redux_block_count(65537, 65536) == 2
+    assert L.redux_block_count(148481, 65536) == 3
+    p = _lib.Params(8, 30, 32)
+    slot = L.redux_encode_slot_bytes(C.byref(p), 65536)
+    assert slot >= 65536 * 9 // 8 + 8
+    assert L.redux_encode_bound(C.byref(p), 148481, 65536) == 3 * slot
+    assert L.redux_encode_workspace_bytes(C.byref(p), 148481, 65536) > 3 * slot
+    # a model that freezes inside the block can cost freq_bits+1 bits per symbol
+    p14 = _lib.Params(8, 14, 16)
+    assert L.redux_encode_slot_bytes(C.byref(p14), 65536) >= 65536 * 15 // 8
+
+
+def test_worst_case_slot_bound_holds_on_cpu_oracle():
+    # adversarial input for a frozen model: saturate one symbol, then send only rare ones
+    data = bytes([0]) * 16200 + bytes(range(1, 256)) * 193
+    data = data[:65536]
+    s, _ = ox.compress(data, (8, 14, 16))
+    p14 = _lib.Params(8, 14, 16)
+    assert len(s) <= _lib.lib().redux_encode_slot_bytes(C.byref(p14), 65536)
+    assert len(s) > 65536  # it really expands
+
+
+def test_parameters_mirror():
+    P = api.Parameters(8, 30, 32)
+    q = ox.params_new(8, 30, 32)
+    for k in ("symbol_bits", "symbol_eof", "symbol_count", "freq_bits", "freq_max", "code_bits", "code_min",
+              "code_one_fourth", "code_half", "code_three_fourths", "code_max"):
+        assert getattr(P, k) == getattr(q, k)
+    with pytest.raises(api.InvalidInput):
+        api.Parameters(8, 9, 16)
+    assert api.AdaptiveTreeModel.new(P).parameters() is P
+
+
+def test_zipf_table_properties():
+    th = api.zipf_thresholds()
+    assert th.dtype == np.uint32 and th.shape == (256,)
+    assert (np.diff(th.astype(np.int64)) > 0).all() and th[-1] == 2**32 - 1
+    w = np.arange(1, 257, dtype=np.float64) ** -1.2
+    cdf = np.cumsum(w) / w.sum()
+    assert np.abs(th.astype(np.float64) / 2**32 - cdf).max() < 1e-9
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "redux_amd", "does_not_exist.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        api.compress_blocks(b"abc", 65536)

@@ -1,0 +1,272 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+Bit-exact: integer/byte work, no tolerance anywhere."""
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, corpus_files
+from oracle import cbind as ox
+
+pytestmark = pytest.mark.gpu
+
+WIDTHS = [(8, 14, 16), (8, 22, 24), (8, 30, 32)]
+BLOCK = 65536
+
+
+@pytest.fixture(scope="module")
+def rx():
+    import redux_amd
+    return redux_amd
+
+
+def h64(b):
+    return hashlib.blake2b(bytes(b), digest_size=8).hexdigest()
+
+
+def split(out, offs):
+    return [out[int(offs[i]): int(offs[i + 1])].tobytes() for i in range(len(offs) - 1)]
+
+
+HAND_TRACED = [
+    (b"", (8, 14, 16), "ff00"), (b"", (8, 30, 32), "ff00ff00"),
+    (b"\x61", (8, 14, 16), "619d02"), (b"\x61", (8, 30, 32), "619d64970e"),
+]
+
+
+@pytest.mark.parametrize("data,params,hexs", HAND_TRACED)
+def test_hand_traced_vectors(rx, data, params, hexs):
+    o = io.BytesIO()
+    counts = rx.compress(io.BytesIO(data), o, rx.AdaptiveTreeModel.new(rx.Parameters.new(*params)))
+    assert o.getvalue().hex() == hexs and counts == (len(data), len(hexs) // 2)
+    d = io.BytesIO()
+    dc = rx.decompress(io.BytesIO(o.getvalue()), d, rx.AdaptiveTreeModel.new(rx.Parameters.new(*params)))
+    assert d.getvalue() == data and dc == (len(hexs) // 2, len(data))
+
+
+def test_doctest_roundtrip(rx):  # src/lib.rs:23-39
+    data = bytes([0x72, 0x65, 0x64, 0x75, 0x78])
+    model = rx.AdaptiveTreeModel.new(rx.Parameters.new(8, 14, 16))
+    comp = io.BytesIO()
+    rx.compress(io.BytesIO(data), comp, model)
+    dec = io.BytesIO()
+    rx.decompress(io.BytesIO(comp.getvalue()), dec, model)
+    assert dec.getvalue() == data
+    assert comp.getvalue() == ox.compress(data, (8, 14, 16))[0]
+
+
+def test_kat_streams(rx):
+    for k in json.load(open(os.path.join(GOLDEN, "kat_streams.json"))):
+        data = bytes.fromhex(k["input_hex"])
+        out, offs, st = rx.compress_blocks(data, max(len(data), 1), tuple(k["params"]))
+        assert out.tobytes().hex() == k["stream_hex"], k["name"]
+
+
+@pytest.mark.parametrize("key,path", corpus_files("artificial", "calgary", "canterbury"))
+def test_corpus_blocks_bit_exact_and_roundtrip(rx, key, path):  # BASELINE.json config 3
+    data = open(path, "rb").read()
+    gold = json.load(open(os.path.join(GOLDEN, "blocks.json")))[key]
+    for w in WIDTHS:
+        out, offs, st = rx.compress_blocks(data, BLOCK, w)
+        streams = split(out, offs)
+        g = gold["%d_%d_%d" % w]
+        assert [len(s) for s in streams] == g["block_sizes"], (key, w)
+        assert [h64(s) for s in streams] == g["block_hashes"], (key, w)
+        dec, sizes, dst = rx.decompress_blocks(out, offs, BLOCK, w)
+        got = b"".join(dec[b * BLOCK: b * BLOCK + int(sizes[b])].tobytes() for b in range(len(sizes)))
+        assert got == data, (key, w)
+    # direct comparison with the oracle (not only hashes) at the CLI's parameters
+    want, stw = ox.compress_blocks(data, BLOCK, (8, 30, 32), nthreads=4)
+    out, offs, st = rx.compress_blocks(data, BLOCK, (8, 30, 32))
+    assert split(out, offs) == want
+
+
+@pytest.mark.parametrize("key", ["large/bible.txt", "large/world192.txt", "misc/pi.txt"])
+def test_large_files_blocks(rx, key):  # BASELINE.json config 4 inputs, single GPU
+    data = open(os.path.join(GOLDEN, "corpora", key), "rb").read()
+    gold = json.load(open(os.path.join(GOLDEN, "blocks.json")))[key]["8_30_32"]
+    out, offs, st = rx.compress_blocks(data, BLOCK, (8, 30, 32))
+    streams = split(out, offs)
+    assert [len(s) for s in streams] == gold["block_sizes"]
+    assert [h64(s) for s in streams] == gold["block_hashes"]
+    dec, sizes, _ = rx.decompress_blocks(out, offs, BLOCK, (8, 30, 32))
+    assert b"".join(dec[b * BLOCK: b * BLOCK + int(sizes[b])].tobytes() for b in range(len(sizes))) == data
+
+
+@pytest.mark.parametrize("key", ["canterbury/alice29.txt", "calgary/geo", "artificial/aaa.txt", "calgary/pic"])
+def test_whole_stream_equals_reference_semantics(rx, key):  # config 1: one stream, any length (u32 tree path)
+    data = open(os.path.join(GOLDEN, "corpora", key), "rb").read()
+    gold = json.load(open(os.path.join(GOLDEN, "blocks.json")))[key]
+    for w in WIDTHS:
+        o = io.BytesIO()
+        counts = rx.compress(io.BytesIO(data), o, rx.Parameters(*w))
+        g = gold["%d_%d_%d" % w]
+        assert counts == (len(data), g["whole_size"]) and h64(o.getvalue()) == g["whole_hash"], (key, w)
+        d = io.BytesIO()
+        dc = rx.decompress(io.BytesIO(o.getvalue()), d, rx.Parameters(*w), max_output=len(data) + 64)
+        assert d.getvalue() == data and dc == (g["whole_size"], len(data))
+
+
+EDGE_LENGTHS = [0, 1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 255, 256, 257, 1000, 4095, 4096, 4097]
+
+
+@pytest.mark.parametrize("block_size", [16, 48, 1000, 4096, 65536])
+def test_ragged_and_small_blocks(rx, block_size):
+    rnd = np.random.default_rng(block_size)
+    for n in EDGE_LENGTHS + [3 * block_size, 3 * block_size + 1, 5 * block_size - 1]:
+        data = rnd.integers(0, 256, n, dtype=np.uint8).tobytes()
+        for w in WIDTHS:
+            out, offs, st = rx.compress_blocks(data, block_size, w)
+            want, _ = ox.compress_blocks(data, block_size, w)
+            assert split(out, offs) == want, (n, block_size, w)
+            dec, sizes, _ = rx.decompress_blocks(out, offs, block_size, w)
+            got = b"".join(dec[b * block_size: b * block_size + int(sizes[b])].tobytes() for b in range(len(sizes)))
+            assert got == data
+
+
+def test_many_ragged_lanes_in_one_wave(rx):
+    # 200 blocks of 1000 bytes + a short last block: lanes of one wave finish at different steps
+    rnd = np.random.default_rng(7)
+    data = rnd.integers(0, 7, 200 * 1000 + 123, dtype=np.uint8).tobytes()
+    out, offs, st = rx.compress_blocks(data, 1000, (8, 30, 32))
+    want, _ = ox.compress_blocks(data, 1000, (8, 30, 32))
+    assert split(out, offs) == want
+    dec, sizes, _ = rx.decompress_blocks(out, offs, 1000, (8, 30, 32))
+    assert b"".join(dec[b * 1000: b * 1000 + int(sizes[b])].tobytes() for b in range(len(sizes))) == data
+
+
+STRESS = {
+    "all_ff_64k": bytes([255]) * 65536,            # deepest update chain, u16 node reaches 65535
+    "all_00_64k": bytes([0]) * 65536,
+    "two_symbols": bytes([0, 255]) * 32768,
+    "ramp": bytes(range(256)) * 256,
+    "skewed": (bytes([7]) * 63 + bytes([200])) * 1024,
+    "freeze_then_rare": (bytes([0]) * 16200 + bytes(range(1, 256)) * 194)[:65536],
+}
+
+
+@pytest.mark.parametrize("name", sorted(STRESS))
+def test_stress_patterns(rx, name):  # pending-run / carry and freeze corner cases
+    data = STRESS[name]
+    for w in WIDTHS + [(8, 10, 16), (8, 16, 18), (8, 17, 19)]:
+        out, offs, st = rx.compress_blocks(data, BLOCK, w)
+        want, _ = ox.compress_blocks(data, BLOCK, w, slot=200000)
+        assert split(out, offs) == want, (name, w)
+        dec, sizes, _ = rx.decompress_blocks(out, offs, BLOCK, w)
+        assert dec[: int(sizes[0])].tobytes() == data, (name, w)
+
+
+def test_random_param_sweep(rx):
+    rnd = np.random.default_rng(99)
+    for trial in range(12):
+        fb = int(rnd.integers(10, 31))
+        cb = int(rnd.integers(fb + 2, min(32, 64 - fb) + 1))
+        n = int(rnd.integers(1, 30000))
+        alpha = int(rnd.integers(2, 257))
+        data = rnd.integers(0, alpha, n, dtype=np.uint8).tobytes()
+        bs = int(rnd.choice([512, 4096, 65536]))
+        out, offs, st = rx.compress_blocks(data, bs, (8, fb, cb))
+        want, _ = ox.compress_blocks(data, bs, (8, fb, cb), slot=4 * bs + 4096)
+        assert split(out, offs) == want, (fb, cb, n, bs)
+        dec, sizes, _ = rx.decompress_blocks(out, offs, bs, (8, fb, cb))
+        assert b"".join(dec[b * bs: b * bs + int(sizes[b])].tobytes() for b in range(len(sizes))) == data
+
+
+def test_error_paths(rx):
+    data = open(os.path.join(GOLDEN, "corpora", "canterbury", "xargs.1"), "rb").read()
+    out, offs, st = rx.compress_blocks(data, BLOCK, (8, 30, 32))
+    # truncated stream -> Eof (bitio/mod.rs:107 via codec.rs:50)
+    cut = np.array([0, int(offs[1]) // 2], dtype=np.uint64)
+    dec, sizes, status = rx.decompress_blocks(out[: int(cut[1])], cut, BLOCK, (8, 30, 32), check=False)
+    assert status[0] == 1
+    with pytest.raises(rx.Eof):
+        rx.decompress_blocks(out[: int(cut[1])], cut, BLOCK, (8, 30, 32))
+    # stream shorter than code_bits
+    dec, sizes, status = rx.decompress_blocks(out[:2], np.array([0, 2], dtype=np.uint64), BLOCK, (8, 30, 32), check=False)
+    assert status[0] == 1 and sizes[0] == 0
+    # decoded data larger than the block capacity
+    dec, sizes, status = rx.decompress_blocks(out, offs, 1024, (8, 30, 32), check=False)
+    assert status[0] == 4
+    # parameters
+    with pytest.raises(rx.InvalidInput):
+        rx.compress_blocks(data, BLOCK, (8, 9, 16))
+    with pytest.raises(rx.Unsupported):
+        rx.compress_blocks(data, BLOCK, (4, 10, 16))
+    with pytest.raises(rx.Unsupported):
+        rx.compress_blocks(data, BLOCK, (8, 24, 40))
+
+
+def test_generators_match_host_definition(rx):
+    import torch
+    n = 1 << 16
+
+    def splitmix(x):
+        x = (x + np.uint64(0x9E3779B97F4A7C15))
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+    with np.errstate(over="ignore"):
+        for first in (0, 8 * 12345, 13):
+            got = rx.gen_iid(n, 0x5EED0001, first).cpu().numpy()
+            j = np.arange(first, first + n, dtype=np.uint64)
+            words = splitmix(np.uint64(0x5EED0001) + (j >> np.uint64(3)))
+            want = ((words >> ((j & np.uint64(7)) * np.uint64(8))) & np.uint64(0xFF)).astype(np.uint8)
+            assert (got == want).all(), first
+        got = rx.gen_zipf(n, 0x5EED0005, 777).cpu().numpy()
+        j = np.arange(777, 777 + n, dtype=np.uint64)
+        u = (splitmix(np.uint64(0x5EED0005) + j) >> np.uint64(32)).astype(np.uint32)
+        want = np.searchsorted(rx.zipf_thresholds(), u, side="left").astype(np.uint8)
+        assert (got == want).all()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("kind,nblocks", [("iid", 4096), ("zipf", 2048)])
+def test_device_resident_pipeline(rx, kind, nblocks):
+    """Config 2/5 shape at reduced block count, HBM-resident end to end: generate, encode,
+    decode, compare on device; a sample of blocks is compared byte-for-byte with the oracle."""
+    import torch
+    n = nblocks * BLOCK
+    d_in = rx.gen_iid(n) if kind == "iid" else rx.gen_zipf(n)
+    enc = rx.DeviceEncoder((8, 30, 32), BLOCK, n)
+    out, offs, status, summary = enc.encode(d_in)
+    torch.cuda.synchronize()
+    assert summary.tolist() == [0, 0]
+    offs_h = offs.cpu().numpy().astype(np.uint64)
+    total = int(offs_h[-1])
+    sizes = np.diff(offs_h.astype(np.int64))
+    assert (sizes > 0).all()
+    host_in = d_in.cpu().numpy()
+    for b in [0, 1, 63, 64, 65, nblocks // 2, nblocks - 1]:
+        want, _ = ox.compress(host_in[b * BLOCK:(b + 1) * BLOCK].tobytes(), (8, 30, 32))
+        got = out[int(offs_h[b]): int(offs_h[b + 1])].cpu().numpy().tobytes()
+        assert got == want, b
+    dec = rx.DeviceDecoder((8, 30, 32), BLOCK, nblocks)
+    d_out, d_sizes, d_status, d_sum = dec.decode(out[:total], offs)
+    torch.cuda.synchronize()
+    assert d_sum.tolist() == [0, 0]
+    assert bool((d_sizes == BLOCK).all())
+    assert torch.equal(d_out, d_in)
+
+
+def test_dense_output_too_small_is_reported_not_overrun(rx):
+    import ctypes as C
+    import torch
+    from redux_amd import _lib
+    n = 8 * BLOCK
+    d_in = rx.gen_iid(n)
+    enc = rx.DeviceEncoder((8, 30, 32), BLOCK, n)
+    guard = torch.full((1024,), 0xAB, dtype=torch.uint8, device="cuda:0")
+    small = torch.cat([torch.zeros(3 * BLOCK, dtype=torch.uint8, device="cuda:0"), guard])
+    st = _lib.lib().redux_encode_blocks_dev(C.byref(enc.cp), C.c_void_p(d_in.data_ptr()), n, BLOCK,
+                                            C.c_void_p(small.data_ptr()), 3 * BLOCK, C.c_void_p(enc.offsets.data_ptr()),
+                                            C.c_void_p(enc.status.data_ptr()), C.c_void_p(enc.summary.data_ptr()),
+                                            enc._ws_ptr(), enc.ws_bytes, None)
+    torch.cuda.synchronize()
+    assert st == 0
+    assert enc.summary[0].item() == 4 and enc.summary[1].item() >= 5
+    assert bool((small[3 * BLOCK:] == 0xAB).all())
