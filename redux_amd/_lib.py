@@ -54,6 +54,15 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m redux_amd.build` "
                 "(there is no CPU fallback for the redux hot path)")
+        # One HIP runtime per process: torch ships its own libamdhip64.so (SONAME
+        # libamdhip64.so.7).  Loaded first, it satisfies this library's NEEDED entry, so both
+        # share a runtime (and device pointers / streams are interchangeable).  Loaded second,
+        # torch would bring a second runtime that cannot open the device.  A consumer without
+        # torch (plain C/C++) gets the system ROCm runtime through the library's RUNPATH.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if the library does not export it
