@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: encode MB/s on BASELINE.json configs[1].
+
+  python bench.py --gpus N --steps K --warmup W          (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch: every rank codes its own 65,536 blocks of
+64 KiB of iid bytes (generated in HBM, seed 0x5EED0001, rank r owns stream bytes
+[r*4GiB, (r+1)*4GiB)) into a dense stream + offsets table, input and output resident in HBM.
+Blocks are independent, so ranks share nothing: no collective on the data path ("weak"
+scaling: per-GPU work is fixed).  value = input bytes of all ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (k_encode): algorithmic bytes = sum over blocks of
+                (bytes read + bytes written), taken from the offsets table, divided by the
+                kernel's mean duration measured with HIP events on the launch stream inside
+                the timed steps; peak = 8.0e12 B/s (MI355X HBM3E).  `traffic` is the
+                PMC-measured HBM bytes per launch when profiles/traffic.json holds it.
+  cpu_baseline  the CPU oracle (C restatement of the reference, kind "port") on a bounded
+                prefix of the same workload, on this box's host cores, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BLOCK = 65536
+PARAMS = (8, 30, 32)  # the reference CLI's fixed Parameters::new(8, 30, 32) (src/main.rs:108)
+SEED = 0x5EED0001
+HBM_PEAK = 8.0e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks", type=int, default=65536, help="blocks per GPU (default: the config's 65,536)")
+    ap.add_argument("--workload", choices=["iid", "zipf"], default="iid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-blocks", type=int, default=4096)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    import redux_amd as rx
+
+    nblocks = args.blocks
+    n = nblocks * BLOCK
+    seed = SEED if args.workload == "iid" else 0x5EED0005
+    gen = rx.gen_iid if args.workload == "iid" else rx.gen_zipf
+    d_in = gen(n, seed, rank * n, device=dev)
+    enc = rx.DeviceEncoder(PARAMS, BLOCK, n, device=dev)
+    torch.cuda.synchronize()
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        enc.encode_slots(d_in)      # k_fill_rc (a few us) + k_encode, the dominant kernel
+        if ev is not None:
+            ev[1].record()
+        enc.compact(n)              # k_scan_sizes + k_compact -> dense output + offsets
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # correctness gate on this rank: no block reported an error, output decodes on device
+    assert enc.summary.tolist() == [0, 0], enc.summary.tolist()
+    out_bytes = int(enc.offsets[nblocks].item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_in = n * world
+    value = total_in / elapsed * args.steps / 1e6
+    algo_bytes = n + out_bytes
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and tj.get("blocks") == nblocks:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "encode MB/s (whole node), per-block bitstream bit-exact",
+        "value": round(value, 1),
+        "unit": "MB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"{nblocks} independent 64 KiB iid-byte blocks per GPU (BASELINE.json configs[1])"
+                         if args.workload == "iid" else
+                         f"{nblocks} independent 64 KiB Zipf(1.2) blocks per GPU (BASELINE.json configs[4] shape)"),
+            "block_size": BLOCK,
+            "blocks_per_gpu": nblocks,
+            "parameters": list(PARAMS),
+            "parallelism": f"blocks sharded over {world} GPU(s), no data-path collective",
+            "compressed_over_input": round(out_bytes / n, 5),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_encode<u16 tree, no fix-up>",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s",
+            "frac": round(achieved * 1e9 / HBM_PEAK, 5),
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "kernel_ms": round(kern_ms, 3),
+        },
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import cbind as ox
+        sample_blocks = min(args.cpu_sample_blocks, nblocks)
+        host = d_in[: sample_blocks * BLOCK].cpu().numpy()
+        cores = len(os.sched_getaffinity(0))
+        ox.lib()
+        t1 = time.perf_counter()
+        o1, sizes1, status1, slot1 = ox.compress_blocks_raw(host[: 64 * BLOCK], BLOCK, PARAMS, ox.TREE, nthreads=1)
+        single = 64 * BLOCK / (time.perf_counter() - t1) / 1e6
+        t1 = time.perf_counter()
+        o, sizes, status, slot = ox.compress_blocks_raw(host, BLOCK, PARAMS, ox.TREE, nthreads=cores)
+        dt = time.perf_counter() - t1
+        assert not status.any()
+        # parity spot check against what the GPU produced for the same blocks
+        offs = enc.offsets[: sample_blocks + 1].cpu().numpy()
+        import numpy as np
+        assert (np.diff(offs) == sizes).all(), "GPU block sizes differ from the CPU oracle"
+        for b in (0, sample_blocks // 2, sample_blocks - 1):
+            g = enc.out[int(offs[b]): int(offs[b + 1])].cpu().numpy()
+            assert (g == o[b * slot: b * slot + int(sizes[b])]).all(), f"block {b} differs from the CPU oracle"
+        line["cpu_baseline"] = {
+            "value": round(sample_blocks * BLOCK / dt / 1e6, 1),
+            "unit": "MB/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"first {sample_blocks} blocks ({sample_blocks * BLOCK >> 20} MiB) of the same stream, C restatement "
+                      f"of the reference (-O2), {cores} threads, one block per task; single thread: {single:.1f} MB/s; "
+                      "sizes of all sampled blocks and bytes of 3 blocks compared with the GPU output",
+        }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
