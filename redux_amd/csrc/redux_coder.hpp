@@ -13,6 +13,11 @@
 //   bit I/O src/bitio/mod.rs:148-198, :78-120    (MSB-first packing, zero padding)
 // HOW it is computed is different everywhere; each routine below states the identity it
 // relies on.
+//
+// Issue economics that shape the code: the tree (512 B per block) caps residency at 4-5
+// waves per CU, i.e. ONE wave per SIMD.  A lone wave issues one instruction -- VALU or SALU
+// -- per ~4 cycles with nothing to hide behind, so the hot path minimises instruction COUNT
+// and avoids branches.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -21,6 +26,7 @@
 namespace redux {
 
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) double *rc_ptr; // forces scalar (SMEM) loads
 
 // --------------------------------------------------------------------------------------
 // Frequency tree in LDS.
@@ -39,115 +45,106 @@ typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 // eight independent LDS reads serves both ends of the range (adaptive_tree.rs:63-80).
 //
 // Two layouts:
-//   U16: d[] as u16, two LANES per dword: dword index = e*32 + (lane>>1), half = lane&1.
+//   U16: d[] as u16, two LANES per dword: byte address = e*128 + 4*(lane>>1), half = lane&1.
 //        32 KiB per wave -> 4 waves (one per SIMD) + staging fit the CU's 160 KiB.  Valid while
 //        every d[] stays < 65536: blocks of <= 65536 symbols with the (unobservable) update
-//        of a block's last symbol skipped.
-//   U32: d[] as u32, dword index = e*64 + lane.  64 KiB per wave; any block length.
+//        of a block's last symbol skipped.  Lanes 2m and 2m+1 share a bank (2-way conflict on
+//        differing rows); LDS cycles are not what bounds this kernel.
+//   U32: d[] as u32, byte address = e*256 + 4*lane.  64 KiB per wave; any block length.
 // --------------------------------------------------------------------------------------
 template <bool U16>
-struct Tree;
+struct Tree {
+    static constexpr uint32_t kDwords = U16 ? 256 * 32 : 256 * 64;
+    static constexpr int      kShift  = U16 ? 7 : 8; // log2(row bytes)
 
-template <>
-struct Tree<true> {
-    static constexpr uint32_t kDwords = 256 * 32;
-    uint32_t *t;
-    uint32_t  col;   // lane >> 1
-    uint32_t  inc;   // 1 or 0x10000: +1 in this lane's half
-    uint32_t  sel;   // v_perm selector picking this lane's half of two dwords
+    uint32_t *lds;
+    uint32_t  A[8]; // per-level address constant: (1 << (b + kShift)) | column
+    uint32_t  L;    // this lane's column (byte offset inside a row)
+    uint32_t  inc;  // +1 in this lane's slot of the dword
+    uint32_t  sel;  // U16: v_perm selector picking this lane's halves of two dwords
 
-    __device__ __forceinline__ void init(uint32_t *lds, uint32_t lane)
+    __device__ __forceinline__ void init(uint32_t *p, uint32_t lane)
     {
-        t   = lds;
-        col = lane >> 1;
-        inc = (lane & 1) ? 0x10000u : 1u;
+        lds = p;
+        L   = U16 ? (lane >> 1) * 4u : lane * 4u;
+        inc = (U16 && (lane & 1)) ? 0x10000u : 1u;
         sel = (lane & 1) ? 0x07060302u : 0x05040100u;
-    }
-    __device__ __forceinline__ uint32_t idx(uint32_t e) const { return e * 32u + col; }
-    __device__ __forceinline__ void bump(uint32_t e) const
-    {
-        __hip_atomic_fetch_add(&t[idx(e)], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    // (low, high) of get_frequency_range(s) given d256 = number of updates so far.
-    __device__ __forceinline__ void range(uint32_t s, uint32_t d256, uint32_t e[8], uint32_t &lo, uint32_t &hi) const
-    {
-        uint32_t x[8];
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            e[b] = (s & ((0xFFu << b) & 0xFFu)) | (1u << b);
-            x[b] = t[idx(e[b])];
+            A[b] = (1u << (b + kShift)) | L;
+            // keep A[b] an opaque VGPR: otherwise the compiler peels the constant into the
+            // ds offset field and spends two more VALU ops per level re-attaching the column
+            asm volatile("" : "+v"(A[b]));
         }
-        const uint32_t m  = s + 1;
-        const u16x2    sv = __builtin_bit_cast(u16x2, s | (s << 16));
-        const u16x2    mv = __builtin_bit_cast(u16x2, m | (m << 16));
-        uint32_t       ls = s, hs = m;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            // [lo16 = this lane's d[e_2j], hi16 = this lane's d[e_2j+1]]
-            const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(x[2 * j + 1], x[2 * j], sel));
-            const u16x2 sh = {(uint16_t)(2 * j), (uint16_t)(2 * j + 1)};
-            const u16x2 one = {1, 1};
-            ls = __builtin_amdgcn_udot2(pv, (sv >> sh) & one, ls, false);
-            hs = __builtin_amdgcn_udot2(pv, (mv >> sh) & one, hs, false);
-        }
-        lo = ls;
-        hi = hs + (s == 255u ? d256 : 0u); // bit 8 of s+1: the derived node 256
     }
-    // value of node e for this lane (decode descent)
-    __device__ __forceinline__ uint32_t node(uint32_t e) const
+    __device__ __forceinline__ uint32_t ld(uint32_t byte_addr) const
     {
-        const uint32_t w = t[idx(e)];
-        return (inc == 1u) ? (w & 0xFFFFu) : (w >> 16);
+        return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + byte_addr);
     }
-};
+    __device__ __forceinline__ void add(uint32_t byte_addr, uint32_t v) const
+    {
+        __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + byte_addr), v,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // node address for level b of symbol s: one v_and_or_b32
+    __device__ __forceinline__ uint32_t addr(uint32_t ss, int b) const
+    {
+        return (ss & (((0xFFu << b) & 0xFFu) << kShift)) | A[b];
+    }
+    // this lane's value of the node at byte_addr (decode descent)
+    __device__ __forceinline__ uint32_t node(uint32_t byte_addr) const
+    {
+        const uint32_t w = ld(byte_addr);
+        return U16 ? ((inc == 1u) ? (w & 0xFFFFu) : (w >> 16)) : w;
+    }
 
-template <>
-struct Tree<false> {
-    static constexpr uint32_t kDwords = 256 * 64;
-    uint32_t *t;
-    uint32_t  lane;
-
-    __device__ __forceinline__ void init(uint32_t *lds, uint32_t l)
+    // get_frequency(s) of adaptive_tree.rs:105-113 for a byte s: (low, high) of the range
+    // query, then -- if upd -- update(s+1).  d256 = number of updates so far.
+    // The update is eight unconditional ds_add_u32 whose addend is this lane's +1 or 0:
+    // node address > symbol address  <=>  e_b > s  <=>  bit b of s is clear.
+    template <bool UPD>
+    __device__ __forceinline__ void get_frequency(uint32_t s, uint32_t d256, bool upd, uint32_t &lo,
+                                                  uint32_t &hi) const
     {
-        t    = lds;
-        lane = l;
-    }
-    __device__ __forceinline__ uint32_t idx(uint32_t e) const { return e * 64u + lane; }
-    __device__ __forceinline__ void bump(uint32_t e) const
-    {
-        __hip_atomic_fetch_add(&t[idx(e)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __device__ __forceinline__ void range(uint32_t s, uint32_t d256, uint32_t e[8], uint32_t &lo, uint32_t &hi) const
-    {
-        uint32_t x[8];
+        const uint32_t ss = s << kShift;
+        uint32_t       a[8], x[8];
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            e[b] = (s & ((0xFFu << b) & 0xFFu)) | (1u << b);
-            x[b] = t[idx(e[b])];
+            a[b] = addr(ss, b);
+            x[b] = ld(a[b]);
+        }
+        if (UPD) {
+            const uint32_t sa = ss | L;
+            const uint32_t iv = upd ? inc : 0u;
+#pragma unroll
+            for (int b = 0; b < 8; b++)
+                add(a[b], a[b] > sa ? iv : 0u);
         }
         const uint32_t m  = s + 1;
         uint32_t       ls = s, hs = m;
+        if (U16) {
+            const u16x2 sv = __builtin_bit_cast(u16x2, s * 0x10001u);
+            const u16x2 mv = __builtin_bit_cast(u16x2, m * 0x10001u);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            ls += ((s >> b) & 1u) ? x[b] : 0u;
-            hs += ((m >> b) & 1u) ? x[b] : 0u;
+            for (int j = 0; j < 4; j++) {
+                // [lo16 = this lane's d[e_2j], hi16 = this lane's d[e_2j+1]]
+                const u16x2 pv  = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(x[2 * j + 1], x[2 * j], sel));
+                const u16x2 sh  = {(uint16_t)(2 * j), (uint16_t)(2 * j + 1)};
+                const u16x2 one = {1, 1};
+                ls = __builtin_amdgcn_udot2(pv, (sv >> sh) & one, ls, false);
+                hs = __builtin_amdgcn_udot2(pv, (mv >> sh) & one, hs, false);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                ls += ((s >> b) & 1u) ? x[b] : 0u;
+                hs += ((m >> b) & 1u) ? x[b] : 0u;
+            }
         }
         lo = ls;
-        hi = hs + (s == 255u ? d256 : 0u);
+        hi = hs + (m >> 8) * d256; // bit 8 of s+1 selects the derived node 256
     }
-    __device__ __forceinline__ uint32_t node(uint32_t e) const { return t[idx(e)]; }
 };
-
-// update(s+1) of adaptive_tree.rs:83-92 restricted to the stored nodes: +1 on every level
-// whose bit of s is clear (e_b > s  <=>  bit b of s is clear).
-template <bool U16>
-__device__ __forceinline__ void tree_update(const Tree<U16> &T, uint32_t s, const uint32_t e[8])
-{
-#pragma unroll
-    for (int b = 0; b < 8; b++)
-        if (e[b] > s)
-            T.bump(e[b]);
-}
 
 // --------------------------------------------------------------------------------------
 // floor((R1+1) * f / c) mod 2^32 for the wave-uniform divisor c (codec.rs:59-60, :133-134).
@@ -173,43 +170,47 @@ __device__ __forceinline__ uint32_t scale_div(uint32_t R1, double Y, uint32_t f,
 }
 
 // --------------------------------------------------------------------------------------
-// Encoder lane state.  low/high are kept LEFT-ALIGNED in 32 bits (value << sh, high padded
-// with ones, sh = 32 - code_bits), which makes the renormalisation independent of code_bits.
+// Encoder lane state.  low and ~high are kept LEFT-ALIGNED in 32 bits (value << sh, high
+// padded with ones, sh = 32 - code_bits), which makes renormalisation independent of
+// code_bits.  Output goes through a 64-bit accumulator; completed 32-bit groups are stored
+// big-endian (MSB-first stream, bitio/mod.rs:148-181) at wave-uniform base + 32-bit offset.
+// Stores at or beyond `limit` are dropped but still counted, so an overflowing block ends
+// with off > limit and is reported, never written out of bounds.
 // --------------------------------------------------------------------------------------
 struct EncState {
-    uint32_t low, high;
+    uint32_t low, ihigh;
     uint32_t pend; // pending (E3) bit count, codec.rs:18
-    uint32_t nb;   // valid bits in acc (< 32 between calls)
-    uint32_t pos;  // bytes emitted so far (multiple of 4 until the final flush)
-    uint64_t acc;  // bit accumulator, newest bit at bit 0
+    uint32_t nb;   // bits waiting in acc (< 32 between symbols)
+    uint32_t off;  // byte offset of the next dword from the wave's uniform base
+    uint64_t acc;  // newest bit at bit 0
 };
 
-// BitWriter::write_bits for m <= 32 bits (bitio/mod.rs:148-181): MSB-first, so a completed
-// 32-bit group is stored big-endian.  Stores beyond cap are dropped but still counted, so an
-// overflowing block ends with pos > cap and is reported, never written out of bounds.
-__device__ __forceinline__ void put_bits(EncState &S, uint32_t val, uint32_t m, uint8_t *out, uint32_t cap)
+__device__ __forceinline__ void enc_init(EncState &S, uint32_t off0) // codec.rs:28-36
 {
-    S.acc = (S.acc << m) | val;
-    S.nb += m;
-    if (S.nb >= 32) {
-        const uint32_t w = (uint32_t)(S.acc >> (S.nb - 32));
-        if (S.pos + 4 <= cap)
-            *reinterpret_cast<uint32_t *>(out + S.pos) = __builtin_bswap32(w);
-        S.pos += 4;
-        S.nb -= 32;
-    }
+    S.low = 0; S.ihigh = 0; S.pend = 0; S.nb = 0; S.off = off0; S.acc = 0;
 }
 
-__device__ __forceinline__ void put_run(EncState &S, uint32_t bit, uint32_t n, uint8_t *out, uint32_t cap)
+__device__ __forceinline__ void put_bits(EncState &S, uint32_t val, uint32_t m, uint8_t *wbase, uint32_t limit)
+{
+    S.acc = (S.acc << m) | val; // m <= 32
+    const uint32_t nb = S.nb + m;
+    if (nb >= 32 && S.off < limit)
+        *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb - 32)));
+    S.off += (nb >> 5) << 2;
+    S.nb = nb & 31u;
+}
+
+__device__ __forceinline__ void put_run(EncState &S, uint32_t bit, uint32_t n, uint8_t *wbase, uint32_t limit)
 {
     while (n > 0) {
         const uint32_t m = n < 32 ? n : 32;
-        put_bits(S, bit ? (0xFFFFFFFFu >> (32 - m)) : 0u, m, out, cap);
+        put_bits(S, bit ? (0xFFFFFFFFu >> (32 - m)) : 0u, m, wbase, limit);
         n -= m;
     }
 }
 
-// compress_symbol (codec.rs:55-101) for one lane, given the model's (lo, hi, count).
+// compress_symbol (codec.rs:55-89) for one lane, given the model's (lo, hi, count).
+// Returns the number of renormalisation shifts (needed by the EOF tail only).
 //
 // Renormalisation in closed form.  The reference loop (codec.rs:62-89) does, per iteration,
 // E1/E2 (emit the common top bit) or E3 (low in the 2nd quarter, high in the 3rd: count a
@@ -221,63 +222,113 @@ __device__ __forceinline__ void put_run(EncState &S, uint32_t bit, uint32_t n, u
 // and "b followed by P copies of !b" is the number (2^P - 1) + b, so the whole string is
 //     top_k_bits(low) + ((2^P - 1) << (k-1))     in k + P bits.
 template <bool FIXUP>
-__device__ __forceinline__ void encode_symbol(EncState &S, uint32_t lo, uint32_t hi, uint32_t c, double rc,
-                                              uint32_t sh, bool is_eof, uint8_t *out, uint32_t cap)
+__device__ __forceinline__ uint32_t encode_symbol(EncState &S, uint32_t lo, uint32_t hi, uint32_t c, double rc,
+                                                  uint32_t sh, bool is_eof, uint8_t *wbase, uint32_t limit)
 {
-    const uint32_t R1 = (S.high - S.low) >> sh; // range - 1
+    const uint32_t R1 = (~(S.ihigh + S.low)) >> sh; // high - low = ~ihigh - low = ~(ihigh + low)
     const double   Y  = __builtin_fma((double)R1, rc, rc);
-    const uint32_t ql = scale_div<FIXUP>(R1, Y, lo, c);
+    const uint32_t nlow = S.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
     // EOF has hi == c: floor(range*c/c) = range, high is unchanged (and 2^32 would not fit).
-    const uint32_t nhigh = is_eof ? S.high : S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh) - 1u;
-    const uint32_t nlow  = S.low + (ql << sh);
+    const uint32_t nihigh = is_eof ? S.ihigh : ~(S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh) - 1u);
 
-    const uint32_t x  = nlow ^ nhigh;
-    const uint32_t k  = x ? (uint32_t)__builtin_clz(x) : 32u;
-    const uint64_t sl = (uint64_t)nlow << k;
-    const uint32_t topk  = (uint32_t)(sl >> 32);           // the k shared leading bits
-    const uint32_t low2  = (uint32_t)sl;
-    const uint32_t ihigh2 = (uint32_t)((uint64_t)(~nhigh) << k); // ~high2 (ones shifted in)
-    const uint32_t t  = (low2 & ihigh2) << 1;
-    const uint32_t j  = (uint32_t)__builtin_clz(~t);       // ~t has bit 0 set: never zero
-    S.low  = (low2 << j) & 0x7FFFFFFFu;
-    S.high = ~((ihigh2 << j) & 0x7FFFFFFFu);
+    const uint32_t x    = ~(nlow ^ nihigh); // low ^ high
+    const uint32_t k    = x ? (uint32_t)__builtin_clz(x) : 32u;
+    const uint64_t sl   = (uint64_t)nlow << k;
+    const uint32_t topk = (uint32_t)(sl >> 32); // the k shared leading bits
+    const uint32_t low2 = (uint32_t)sl;
+    const uint32_t ih2  = (uint32_t)((uint64_t)nihigh << k); // ~high2: ones shifted into high
+    const uint32_t t    = (low2 & ih2) << 1;
+    const uint32_t j    = (uint32_t)__builtin_clz(~t); // ~t has bit 0 set: never zero
+    S.low   = (low2 << j) & 0x7FFFFFFFu;
+    S.ihigh = (ih2 << j) & 0x7FFFFFFFu;
 
-    const uint32_t P = S.pend;
-    if (k > 0) {
-        if (k + P <= 32) {
-            put_bits(S, topk + (((1u << P) - 1u) << (k - 1)), k + P, out, cap);
-        } else { // long pending run: rare, bit-serial in spirit
-            put_bits(S, topk >> (k - 1), 1, out, cap);
-            put_run(S, (topk >> (k - 1)) ^ 1u, P, out, cap);
-            put_bits(S, topk & ((1u << (k - 1)) - 1u), k - 1, out, cap);
-        }
-        S.pend = j;
-    } else {
-        S.pend = P + j;
+    const uint32_t P  = S.pend;
+    const uint32_t Pz = k ? P : 0u; // pending bits flushed by this symbol
+    S.pend            = P - Pz + j;
+    if (k + Pz <= 32) {
+        put_bits(S, topk + (((1u << Pz) - 1u) << ((k - 1u) & 31u)), k + Pz, wbase, limit);
+    } else { // long pending run: rare, bit-serial in spirit
+        const uint32_t b = topk >> (k - 1);
+        put_bits(S, b, 1, wbase, limit);
+        put_run(S, b ^ 1u, P, wbase, limit);
+        put_bits(S, topk & ((1u << (k - 1)) - 1u), k - 1, wbase, limit);
     }
+    return k + j;
+}
 
-    if (is_eof) { // codec.rs:91-99
-        const uint32_t cb    = 32 - sh;
-        const uint32_t shifts = k + j;
-        if (shifts < cb) {
-            const uint32_t extra = cb - shifts;
-            const uint32_t b     = S.low >> 31;
-            put_bits(S, b, 1, out, cap);
-            put_run(S, b ^ 1u, S.pend, out, cap);
-            S.pend = 0;
-            const uint32_t rest = extra - 1;
-            if (rest > 0)
-                put_bits(S, (S.low << 1) >> (32 - rest), rest, out, cap);
+// Hot-loop version of encode_symbol for data symbols (never EOF), all 64 lanes active.
+// Differences from encode_symbol, none of them visible in the stream:
+//   * the dword store is UNCONDITIONAL and speculative: every symbol stores the accumulator's
+//     current top 32 bits at `off`; `off` only advances once a group is complete, so the last
+//     store at any offset is always the completed group (earlier ones are overwritten in
+//     L2).  This removes the compare + exec-mask save/restore around a predicated store.
+//     The caller guarantees off + 4 <= limit for the whole chunk.
+//   * the long-pending-run case is detected with one wave-level ballot.
+template <bool FIXUP>
+__device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uint32_t hi, uint32_t c, double rc,
+                                                   uint32_t sh, uint8_t *wbase)
+{
+    const uint32_t R1 = (~(S.ihigh + S.low)) >> sh;
+    const double   Y  = __builtin_fma((double)R1, rc, rc);
+    const uint32_t nlow   = S.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
+    const uint32_t nihigh = ~(S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh) - 1u);
+
+    const uint32_t x    = ~(nlow ^ nihigh);
+    const uint32_t k    = x ? (uint32_t)__builtin_clz(x) : 32u;
+    const uint64_t sl   = (uint64_t)nlow << k;
+    const uint32_t topk = (uint32_t)(sl >> 32);
+    const uint32_t low2 = (uint32_t)sl;
+    const uint32_t ih2  = (uint32_t)((uint64_t)nihigh << k);
+    const uint32_t t    = (low2 & ih2) << 1;
+    const uint32_t j    = (uint32_t)__builtin_clz(~t);
+    S.low   = (low2 << j) & 0x7FFFFFFFu;
+    S.ihigh = (ih2 << j) & 0x7FFFFFFFu;
+
+    const uint32_t P  = S.pend;
+    const uint32_t Pz = k ? P : 0u;
+    S.pend            = P - Pz + j;
+    const uint32_t m  = k + Pz;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m > 32) == 0, 1)) {
+        S.acc = (S.acc << m) | (topk + (((1u << Pz) - 1u) << ((k - 1u) & 31u)));
+        const uint32_t nb = S.nb + m;
+        *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> ((nb - 32u) & 63u)));
+        S.off += (nb >> 5) << 2;
+        S.nb = nb & 31u;
+    } else { // some lane has a pending run too long for one append: careful path for all
+        if (m <= 32) {
+            put_bits(S, topk + (((1u << Pz) - 1u) << ((k - 1u) & 31u)), m, wbase, 0xFFFFFFFFu);
+        } else {
+            const uint32_t b = topk >> (k - 1);
+            put_bits(S, b, 1, wbase, 0xFFFFFFFFu);
+            put_run(S, b ^ 1u, P, wbase, 0xFFFFFFFFu);
+            put_bits(S, topk & ((1u << (k - 1)) - 1u), k - 1, wbase, 0xFFFFFFFFu);
         }
-        // flush_bits (bitio/mod.rs:183-198): left-align the tail and pad with zeros
-        const uint32_t nbytes = (S.nb + 7) >> 3;
-        const uint64_t tail   = S.nb ? (S.acc << (64 - S.nb)) : 0;
-        for (uint32_t i = 0; i < nbytes; i++)
-            if (S.pos + i < cap)
-                out[S.pos + i] = (uint8_t)(tail >> (56 - 8 * i));
-        S.pos += nbytes;
-        S.nb = 0;
     }
+}
+
+// The EOF tail (codec.rs:91-99) + flush_bits (bitio/mod.rs:183-198).  `shifts` is what
+// encode_symbol returned for the EOF symbol.  Returns the block's stream length in bytes.
+__device__ __forceinline__ uint32_t encode_finish(EncState &S, uint32_t shifts, uint32_t cb, uint32_t off0,
+                                                  uint8_t *wbase, uint32_t limit)
+{
+    if (shifts < cb) {
+        const uint32_t extra = cb - shifts;
+        const uint32_t b     = S.low >> 31;
+        put_bits(S, b, 1, wbase, limit);
+        put_run(S, b ^ 1u, S.pend, wbase, limit);
+        S.pend = 0;
+        const uint32_t rest = extra - 1;
+        if (rest > 0)
+            put_bits(S, (S.low << 1) >> (32 - rest), rest, wbase, limit);
+    }
+    const uint32_t nbytes = (S.nb + 7) >> 3;
+    const uint64_t tail   = S.nb ? (S.acc << (64 - S.nb)) : 0; // left-align, zero padding
+    for (uint32_t i = 0; i < nbytes; i++)
+        if (S.off + i < limit)
+            wbase[S.off + i] = (uint8_t)(tail >> (56 - 8 * i));
+    S.off += nbytes;
+    S.nb = 0;
+    return S.off - off0;
 }
 
 } // namespace redux

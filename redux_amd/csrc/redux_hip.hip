@@ -50,6 +50,7 @@ struct EncArgs {
     uint32_t       nfreeze;   // freq_max - 257: number of updates before the freeze
     uint32_t       code_bits;
     uint32_t       aligned16; // in and block_size are 16-byte multiples
+    uint32_t       lanes;     // live lanes per wave: 64, or 1 when 64 slots overflow 32-bit offsets
 };
 
 __device__ __forceinline__ uint32_t wave_min(uint32_t v)
@@ -71,13 +72,40 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return v;
 }
 
+// 16 consecutive symbols of every lane's block, all lanes alive, no EOF: the hot loop body.
+// UPD: the model is still adaptive for the whole chunk (updates so far = q = p + i);
+// otherwise it is frozen (adaptive_tree.rs:84) and nup = nfreeze for every symbol.
+// A pending run longer than 32 bits can add any number of bytes, so the chunk's byte budget
+// is guarded by the caller only for the common path (4 bytes per symbol) plus slack; the
+// careful path inside encode_symbol_fast is entered at most once per such run and the caller
+// re-checks the budget every chunk.
+template <bool U16, bool FIXUP, bool UPD>
+__device__ __forceinline__ void encode_chunk(const Tree<U16> &T, EncState &S, const uint4 cur, uint32_t p,
+                                             uint32_t nfreeze, rc_ptr rc, uint32_t sh, uint8_t *wdst)
+{
+    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+    double         r[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        r[i] = rc[UPD ? p + i : nfreeze];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t s   = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const uint32_t nup = UPD ? p + i : nfreeze; // wave-uniform
+        uint32_t       lo, hi;
+        T.template get_frequency<UPD>(s, nup, true, lo, hi);
+        encode_symbol_fast<FIXUP>(S, lo, hi, 257u + nup, r[i], sh, wdst);
+    }
+}
+
 template <bool U16, bool FIXUP>
 __global__ void __launch_bounds__(64) k_encode(EncArgs a)
 {
     __shared__ uint32_t lds[Tree<U16>::kDwords];
     const uint32_t lane = threadIdx.x;
-    const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
-    const bool     live = blk < a.nblocks;
+    const uint64_t blk0 = (uint64_t)blockIdx.x * a.lanes; // wave-uniform
+    const uint64_t blk  = blk0 + lane;
+    const bool     live = lane < a.lanes && blk < a.nblocks;
 
     for (uint32_t i = lane; i < Tree<U16>::kDwords / 4; i += 64)
         reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
@@ -86,25 +114,31 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
     T.init(lds, lane);
 
     uint32_t len = 0;
-    uint64_t off = 0;
     if (live) {
-        off                = blk * a.block_size;
-        const uint64_t rem = a.in_len - off;
+        const uint64_t rem = a.in_len - blk * a.block_size;
         len                = rem < a.block_size ? (uint32_t)rem : a.block_size;
     }
-    const uint8_t *src = a.in + off;
-    uint8_t       *out = a.slots + (live ? blk : 0) * a.slot_bytes;
-    const uint32_t cap = live ? a.slot_cap : 0;
+    // wave-uniform bases (SGPR pairs) + 32-bit per-lane offsets
+    const uint8_t *wsrc  = a.in + blk0 * a.block_size;
+    const uint32_t soff  = live ? lane * a.block_size : 0u;
+    uint8_t       *wdst  = a.slots + blk0 * a.slot_bytes;
+    // Dead lanes of the last wave run the same instruction stream on block blk0's bytes and
+    // store into the spare slot behind the last real one, so the hot loop needs no predicate.
+    const uint32_t off0  = live ? lane * (uint32_t)a.slot_bytes : (uint32_t)(a.nblocks - blk0) * (uint32_t)a.slot_bytes;
+    const uint32_t limit = off0 + a.slot_cap;
 
-    // Wave-uniform bounds (SGPRs): the lock-step loop covers [0, maxlen]; the fast path
-    // covers whole 16-byte chunks strictly below the shortest live block's last symbol.
+    // The lock-step loop covers [0, maxlen]; the unrolled path covers whole 16-byte chunks
+    // strictly below the shortest live block's last symbol.
     const uint32_t minlen  = __builtin_amdgcn_readfirstlane(wave_min(live ? len : 0xFFFFFFFFu));
+    // bytes the unrolled path may add per chunk without any per-store check: 16 x 4 + slack
+    constexpr uint32_t kChunkBudget = 16 * 4 + 32;
     const uint32_t maxlen  = __builtin_amdgcn_readfirstlane(wave_max(live ? len : 0u));
     const uint32_t sh      = 32 - a.code_bits;
     const uint32_t nfreeze = a.nfreeze;
+    const rc_ptr   rc      = (rc_ptr)a.rc;
 
     EncState S;
-    S.low = 0; S.high = 0xFFFFFFFFu; S.pend = 0; S.nb = 0; S.pos = 0; S.acc = 0; // codec.rs:28-36
+    enc_init(S, off0);
 
     uint32_t p        = 0;
     uint32_t main_end = 0;
@@ -112,51 +146,69 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
         main_end = (minlen - 1) & ~15u;
 
     if (main_end) {
-        uint4 cur = *reinterpret_cast<const uint4 *>(src);
-        for (; p < main_end; p += 16) {
-            uint4 nxt = cur;
-            if (p + 16 < main_end)
-                nxt = *reinterpret_cast<const uint4 *>(src + p + 16);
-            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const uint32_t s   = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                const uint32_t q   = p + i;
-                const uint32_t nup = q < nfreeze ? q : nfreeze; // updates so far (uniform)
-                const double   rc  = a.rc[nup];
-                uint32_t       e[8], lo, hi;
-                T.range(s, nup, e, lo, hi);
-                if (q < nfreeze) // adaptive_tree.rs:84: frozen once count == freq_max
-                    tree_update(T, s, e);
-                encode_symbol<FIXUP>(S, lo, hi, 257u + nup, rc, sh, false, out, cap);
+        // (A) adaptive chunks
+        const uint32_t a_end = main_end < (nfreeze & ~15u) ? main_end : (nfreeze & ~15u);
+        if (p < a_end) {
+            uint4 cur = *reinterpret_cast<const uint4 *>(wsrc + soff);
+            for (; p < a_end; p += 16) {
+                if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit)) {
+                    main_end = p; // a slot is nearly full: finish in the checked tail loop
+                    break;
+                }
+                uint4 nxt = cur;
+                if (p + 16 < a_end)
+                    nxt = *reinterpret_cast<const uint4 *>(wsrc + soff + p + 16);
+                encode_chunk<U16, FIXUP, true>(T, S, cur, p, nfreeze, rc, sh, wdst);
+                cur = nxt;
             }
-            cur = nxt;
+        }
+        // (M) the one chunk that crosses the freeze point, symbol by symbol
+        if (p < main_end && p < nfreeze) {
+            const uint32_t m_end = p + 16;
+            for (; p < m_end; p++) {
+                const uint32_t nup = p < nfreeze ? p : nfreeze;
+                uint32_t       lo, hi;
+                T.template get_frequency<true>(wsrc[soff + p], nup, p < nfreeze, lo, hi);
+                encode_symbol<FIXUP>(S, lo, hi, 257u + nup, rc[nup], sh, false, wdst, limit);
+            }
+        }
+        // (F) frozen chunks: static model, no LDS writes
+        if (p < main_end) {
+            uint4 cur = *reinterpret_cast<const uint4 *>(wsrc + soff + p);
+            for (; p < main_end; p += 16) {
+                if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit)) {
+                    main_end = p;
+                    break;
+                }
+                uint4 nxt = cur;
+                if (p + 16 < main_end)
+                    nxt = *reinterpret_cast<const uint4 *>(wsrc + soff + p + 16);
+                encode_chunk<U16, FIXUP, false>(T, S, cur, p, nfreeze, rc, sh, wdst);
+                cur = nxt;
+            }
         }
     }
 
     // Tail: symbol by symbol with per-lane predicates (ragged lengths, the EOF symbol).
     for (; p <= maxlen; p++) {
         const uint32_t nup = p < nfreeze ? p : nfreeze;
-        const double   rc  = a.rc[nup];
+        const double   r   = rc[nup];
         const uint32_t c   = 257u + nup;
         if (live && p < len) {
-            const uint32_t s = src[p];
-            uint32_t       e[8], lo, hi;
-            T.range(s, nup, e, lo, hi);
+            uint32_t lo, hi;
             // The update of a block's last symbol is never observed (the EOF range is
             // derived), and skipping it keeps every u16 node below 65536.
-            if (p < nfreeze && p + 1 != len)
-                tree_update(T, s, e);
-            encode_symbol<FIXUP>(S, lo, hi, c, rc, sh, false, out, cap);
+            T.template get_frequency<true>(wsrc[soff + p], nup, p < nfreeze && p + 1 != len, lo, hi);
+            encode_symbol<FIXUP>(S, lo, hi, c, r, sh, false, wdst, limit);
         } else if (live && p == len) {
             // EOF symbol (codec.rs:108): cum(256) = count-1, cum(257) = count
-            encode_symbol<FIXUP>(S, c - 1, c, c, rc, sh, true, out, cap);
-            a.sizes[blk]  = S.pos;
-            a.status[blk] = S.pos > cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+            const uint32_t shifts = encode_symbol<FIXUP>(S, c - 1, c, c, r, sh, true, wdst, limit);
+            const uint32_t size   = encode_finish(S, shifts, a.code_bits, off0, wdst, limit);
+            a.sizes[blk]  = size;
+            a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
         }
     }
 }
-
 
 // ======================================================================================
 // decode
@@ -221,6 +273,7 @@ template <bool U16, bool FIXUP>
 __global__ void __launch_bounds__(64) k_decode(DecArgs a)
 {
     __shared__ uint32_t lds[Tree<U16>::kDwords];
+    constexpr int  KS   = Tree<U16>::kShift;
     const uint32_t lane = threadIdx.x;
     const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
     const bool     live = blk < a.nblocks;
@@ -242,13 +295,13 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
     const uint64_t stream_bits = size * 8;
     uint8_t       *dst         = a.out + (live ? blk : 0) * (uint64_t)a.block_size;
     const uint32_t capn        = a.block_size;
+    const rc_ptr   rcp         = (rc_ptr)a.rc;
 
     BitIn B;
     B.init(sp, live ? size : 0);
-    // decompress_symbol's first call pulls code_bits bits into `pending` (codec.rs:124-127)
     // decompress_symbol's first call pulls code_bits bits into `pending` (codec.rs:124-127).
     // W holds that value left-aligned (value << sh), like low/high.
-    uint32_t W = B.take(cb) << sh;
+    uint32_t W        = B.take(cb) << sh;
     uint64_t consumed = cb;
     uint32_t low = 0, high = 0xFFFFFFFFu;
     int32_t  st   = REDUX_OK;
@@ -264,7 +317,7 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
         if (__builtin_amdgcn_readfirstlane(__ballot(!done) == 0))
             break;
         const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
-        const double   rc  = a.rc[nup];
+        const double   rc  = rcp[nup];
         const uint32_t c   = 257u + nup;
         if (!done) {
             // value = ((pending - low + 1) * count - 1) / range      (codec.rs:129-131)
@@ -280,7 +333,9 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
                 else if ((uint64_t)r > (uint64_t)R1)
                     v++;
             }
-            // get_symbol (adaptive_tree.rs:115-136)
+            // get_symbol (adaptive_tree.rs:115-136): the descent probes exactly the nodes
+            // e_b(s); the same eight values give cum(s+1), and the levels where the descent
+            // went left (bit clear) are the ones update(s+1) increments.
             uint32_t lo, hi;
             bool     is_eof = false;
             uint32_t s      = 0;
@@ -289,21 +344,21 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
                 lo     = c - 1;
                 hi     = c;
             } else {
-                uint32_t x[8], e[8];
+                uint32_t x[8], ea[8];
                 uint32_t i = 0, rem = v;
 #pragma unroll
                 for (int b = 7; b >= 0; b--) {
-                    e[b] = i | (1u << b);
-                    x[b] = T.node(e[b]);
+                    ea[b] = (i << KS) | T.A[b];
+                    x[b]  = T.node(ea[b]);
                     const uint32_t tv = (1u << b) + x[b];
                     if (rem >= tv) {
-                        i = e[b];
+                        i |= 1u << b;
                         rem -= tv;
                     }
                 }
                 s  = i;
                 lo = v - rem;
-                const uint32_t m = s + 1;
+                const uint32_t m  = s + 1;
                 uint32_t       hs = m;
 #pragma unroll
                 for (int b = 0; b < 8; b++)
@@ -312,8 +367,7 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
                 if (p < a.nfreeze) {
 #pragma unroll
                     for (int b = 0; b < 8; b++)
-                        if (!((s >> b) & 1u))
-                            T.bump(e[b]);
+                        T.add(ea[b], ((s >> b) & 1u) ? 0u : T.inc);
                 }
             }
             if (is_eof) { // codec.rs:136-138: returns before any renormalisation
@@ -645,7 +699,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.off_rc    = 0;
     g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
     g.off_slots = align_up(g.off_sizes + g.nblocks * 4, 256);
-    g.total     = g.off_slots + g.nblocks * g.slot_bytes;
+    g.total     = g.off_slots + (g.nblocks + 1) * g.slot_bytes; // +1: spare slot for dead lanes
     return g;
 }
 
@@ -737,7 +791,10 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     a.nfreeze    = g.nfreeze;
     a.code_bits  = p->code_bits;
     a.aligned16  = ((((uintptr_t)d_in) & 15) == 0 && (block_size & 15) == 0) ? 1 : 0;
-    const uint32_t grid = (uint32_t)((g.nblocks + 63) / 64);
+    // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset;
+    // otherwise (giant blocks, whole-stream mode) one block per wave.
+    a.lanes = (64ull * g.slot_bytes < (1ull << 32) && 64ull * block_size < (1ull << 32)) ? 64u : 1u;
+    const uint32_t grid = (uint32_t)((g.nblocks + a.lanes - 1) / a.lanes);
     if (g.u16 && !g.fixup)
         k_encode<true, false><<<grid, 64, 0, s>>>(a);
     else if (g.u16)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 CSV output (kernel stats + per-kernel mean of each PMC counter).
+Usage: python tools/pmc_summary.py gpurun_out/prof_<tag> [kernel-substring]"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+sub = sys.argv[2] if len(sys.argv) > 2 else "k_encode"
+for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True)):
+    print("==", os.path.relpath(f, root))
+    for row in csv.DictReader(open(f)):
+        print("  %-60s calls=%s total_ns=%s avg_ns=%s pct=%s" % (row.get("Name", "")[:60], row.get("Calls"),
+              row.get("TotalDurationNs"), row.get("AverageNs"), row.get("Percentage")))
+acc = defaultdict(list)
+for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+    for row in csv.DictReader(open(f)):
+        if sub in row.get("Kernel_Name", ""):
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+print("== counters for kernels matching", sub)
+for k in sorted(acc):
+    v = acc[k]
+    print("  %-24s n=%d mean=%.6g" % (k, len(v), sum(v) / len(v)))
