@@ -211,6 +211,193 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
 }
 
 // ======================================================================================
+// encode, two waves per 64 blocks (the production path for u16 trees)
+//
+// The tree (32 KiB per 64 blocks) caps a CU at four groups of 64 blocks -- one wave per SIMD
+// if a group is one wave, and a lone wave issues one instruction per ~4 cycles.  The model
+// (tree query + update) does not depend on the coder's interval state, so a group is split
+// into a MODEL wave and a CODER wave that share the group's LDS:
+//   wave 0: input bytes -> get_frequency -> (low, high) pairs into an LDS ring
+//   wave 1: ring -> interval narrowing, renormalisation, bit output
+// Eight waves per CU = two per SIMD, so each SIMD always has a second instruction stream to
+// issue from.  The ring holds 2 x 8 symbols x 64 lanes x 8 B = 8 KiB (40 KiB per workgroup,
+// four workgroups = the CU's 160 KiB exactly); one s_barrier per 8 symbols hands a half over.
+// Only LDS traffic must be complete at the hand-off, so the barrier waits on lgkmcnt alone:
+// the coder's stores and the model's prefetch loads stay in flight across it.
+// ======================================================================================
+constexpr uint32_t kRingSlots = 8;                               // symbols per hand-off
+constexpr uint32_t kRingBytes = 2 * kRingSlots * 64 * 8;         // two halves of uint2[8][64]
+
+__device__ __forceinline__ void pair_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool UPD>
+__device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, uint32_t lane, const uint4 cur,
+                                            uint32_t p, uint32_t nfreeze)
+{
+    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t s   = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const uint32_t nup = UPD ? p + i : nfreeze;
+        uint32_t       lo, hi;
+        T.template get_frequency<UPD>(s, nup, true, lo, hi);
+        ring[i * 64 + lane] = make_uint2(lo, hi);
+        if ((i & 7) == 7)
+            pair_barrier();
+    }
+}
+
+// MODE 0: adaptive chunk (reciprocals rc[p..p+15]); MODE 1: frozen chunk (rc[nfreeze])
+template <bool FIXUP, int MODE>
+__device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint32_t lane, uint32_t p,
+                                            uint32_t nfreeze, rc_ptr rc, uint32_t sh, uint8_t *wdst)
+{
+    double r[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        r[i] = rc[MODE == 0 ? p + i : nfreeze];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if ((i & 7) == 0)
+            pair_barrier();
+        const uint2    lh  = ring[i * 64 + lane];
+        const uint32_t nup = MODE == 0 ? p + i : nfreeze;
+        encode_symbol_fast<FIXUP>(S, lh.x, lh.y, 257u + nup, r[i], sh, wdst);
+    }
+}
+
+// any chunk, rolled, every store checked against the slot limit
+template <bool FIXUP>
+__device__ __forceinline__ void coder_chunk_checked(EncState &S, const uint2 *ring, uint32_t lane, uint32_t p,
+                                                    uint32_t nfreeze, rc_ptr rc, uint32_t sh, uint8_t *wdst,
+                                                    uint32_t limit)
+{
+    for (uint32_t i = 0; i < 16; i++) {
+        if ((i & 7) == 0)
+            pair_barrier();
+        const uint2    lh  = ring[i * 64 + lane];
+        const uint32_t q   = p + i;
+        const uint32_t nup = q < nfreeze ? q : nfreeze;
+        encode_symbol<FIXUP>(S, lh.x, lh.y, 257u + nup, rc[nup], sh, false, wdst, limit);
+    }
+}
+
+template <bool FIXUP>
+__global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
+{
+    __shared__ uint32_t lds[Tree<true>::kDwords + kRingBytes / 4];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t blk0 = (uint64_t)blockIdx.x * a.lanes;
+    const uint64_t blk  = blk0 + lane;
+    const bool     live = lane < a.lanes && blk < a.nblocks;
+
+    for (uint32_t i = threadIdx.x; i < Tree<true>::kDwords / 4; i += 128)
+        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    Tree<true> T;
+    T.init(lds, lane);
+    uint2 *ring = reinterpret_cast<uint2 *>(lds + Tree<true>::kDwords);
+
+    uint32_t len = 0;
+    if (live) {
+        const uint64_t rem = a.in_len - blk * a.block_size;
+        len                = rem < a.block_size ? (uint32_t)rem : a.block_size;
+    }
+    const uint8_t *wsrc  = a.in + blk0 * a.block_size;
+    const uint32_t soff  = live ? lane * a.block_size : 0u;
+    uint8_t       *wdst  = a.slots + blk0 * a.slot_bytes;
+    const uint32_t off0  = live ? lane * (uint32_t)a.slot_bytes : (uint32_t)(a.nblocks - blk0) * (uint32_t)a.slot_bytes;
+    const uint32_t limit = off0 + a.slot_cap;
+
+    const uint32_t minlen  = __builtin_amdgcn_readfirstlane(wave_min(live ? len : 0xFFFFFFFFu));
+    const uint32_t maxlen  = __builtin_amdgcn_readfirstlane(wave_max(live ? len : 0u));
+    const uint32_t sh      = 32 - a.code_bits;
+    const uint32_t nfreeze = a.nfreeze;
+    const rc_ptr   rc      = (rc_ptr)a.rc;
+    constexpr uint32_t kChunkBudget = 16 * 4 + 32;
+
+    // both waves derive the same chunk schedule from wave-uniform values
+    uint32_t main_end = 0;
+    if (a.aligned16 && minlen != 0xFFFFFFFFu && minlen > 16)
+        main_end = (minlen - 1) & ~15u;
+    const uint32_t a_end = main_end < (nfreeze & ~15u) ? main_end : (nfreeze & ~15u); // adaptive chunks
+    const uint32_t m_end = (a_end < main_end && a_end < nfreeze) ? a_end + 16 : a_end; // freeze-crossing chunk
+
+    EncState S;
+    enc_init(S, off0);
+
+    if (wave == 0) {
+        // ---------------- model wave ----------------
+        if (main_end) {
+            uint32_t p   = 0;
+            uint4    cur = *reinterpret_cast<const uint4 *>(wsrc + soff);
+            for (; p < a_end; p += 16) {
+                uint4 nxt = cur;
+                if (p + 16 < main_end)
+                    nxt = *reinterpret_cast<const uint4 *>(wsrc + soff + p + 16);
+                model_chunk<true>(T, ring, lane, cur, p, nfreeze);
+                cur = nxt;
+            }
+            for (; p < m_end; p += 16) { // rolled: the update stops in the middle of this chunk
+                for (uint32_t i = 0; i < 16; i++) {
+                    const uint32_t q   = p + i;
+                    const uint32_t nup = q < nfreeze ? q : nfreeze;
+                    uint32_t       lo, hi;
+                    T.template get_frequency<true>(wsrc[soff + q], nup, q < nfreeze, lo, hi);
+                    ring[i * 64 + lane] = make_uint2(lo, hi);
+                    if ((i & 7) == 7)
+                        pair_barrier();
+                }
+                if (p + 16 < main_end)
+                    cur = *reinterpret_cast<const uint4 *>(wsrc + soff + p + 16);
+            }
+            for (; p < main_end; p += 16) {
+                uint4 nxt = cur;
+                if (p + 16 < main_end)
+                    nxt = *reinterpret_cast<const uint4 *>(wsrc + soff + p + 16);
+                model_chunk<false>(T, ring, lane, cur, p, nfreeze);
+                cur = nxt;
+            }
+        }
+    } else {
+        // ---------------- coder wave ----------------
+        uint32_t p = 0;
+        for (; p < main_end; p += 16) {
+            if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit) || (p >= a_end && p < m_end))
+                coder_chunk_checked<FIXUP>(S, ring, lane, p, nfreeze, rc, sh, wdst, limit);
+            else if (p < a_end)
+                coder_chunk<FIXUP, 0>(S, ring, lane, p, nfreeze, rc, sh, wdst);
+            else
+                coder_chunk<FIXUP, 1>(S, ring, lane, p, nfreeze, rc, sh, wdst);
+        }
+    }
+    __syncthreads(); // the model wave's last updates are in LDS before the tail reads the tree
+    if (wave == 0)
+        return;
+
+    // Tail (coder wave only): symbol by symbol with per-lane predicates.
+    for (uint32_t p = main_end; p <= maxlen; p++) {
+        const uint32_t nup = p < nfreeze ? p : nfreeze;
+        const double   r   = rc[nup];
+        const uint32_t c   = 257u + nup;
+        if (live && p < len) {
+            uint32_t lo, hi;
+            T.template get_frequency<true>(wsrc[soff + p], nup, p < nfreeze && p + 1 != len, lo, hi);
+            encode_symbol<FIXUP>(S, lo, hi, c, r, sh, false, wdst, limit);
+        } else if (live && p == len) {
+            const uint32_t shifts = encode_symbol<FIXUP>(S, c - 1, c, c, r, sh, true, wdst, limit);
+            const uint32_t size   = encode_finish(S, shifts, a.code_bits, off0, wdst, limit);
+            a.sizes[blk]  = size;
+            a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+        }
+    }
+}
+
+// ======================================================================================
 // decode
 // ======================================================================================
 struct DecArgs {
@@ -795,7 +982,13 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     // otherwise (giant blocks, whole-stream mode) one block per wave.
     a.lanes = (64ull * g.slot_bytes < (1ull << 32) && 64ull * block_size < (1ull << 32)) ? 64u : 1u;
     const uint32_t grid = (uint32_t)((g.nblocks + a.lanes - 1) / a.lanes);
-    if (g.u16 && !g.fixup)
+    const char *force = getenv("REDUX_ENCODE_KERNEL"); // "single" pins the one-wave kernel (A/B timing only)
+    const bool  pair  = g.u16 && a.aligned16 && a.lanes == 64 && !(force && !strcmp(force, "single"));
+    if (pair && !g.fixup)
+        k_encode_pair<false><<<grid, 128, 0, s>>>(a);
+    else if (pair)
+        k_encode_pair<true><<<grid, 128, 0, s>>>(a);
+    else if (g.u16 && !g.fixup)
         k_encode<true, false><<<grid, 64, 0, s>>>(a);
     else if (g.u16)
         k_encode<true, true><<<grid, 64, 0, s>>>(a);
