@@ -34,6 +34,24 @@ SEED = 0x5EED0001
 HBM_PEAK = 8.0e12
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,6 +61,7 @@ def main():
     ap.add_argument("--workload", choices=["iid", "zipf"], default="iid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-blocks", type=int, default=4096)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: usable cores)")
     args = ap.parse_args()
 
     import torch
@@ -161,7 +180,7 @@ def main():
         from oracle import cbind as ox
         sample_blocks = min(args.cpu_sample_blocks, nblocks)
         host = d_in[: sample_blocks * BLOCK].cpu().numpy()
-        cores = len(os.sched_getaffinity(0))
+        cores = args.cpu_threads or host_cores()
         ox.lib()
         t1 = time.perf_counter()
         o1, sizes1, status1, slot1 = ox.compress_blocks_raw(host[: 64 * BLOCK], BLOCK, PARAMS, ox.TREE, nthreads=1)

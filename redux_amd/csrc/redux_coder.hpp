@@ -45,11 +45,10 @@ typedef const __attribute__((address_space(4))) double *rc_ptr; // forces scalar
 // eight independent LDS reads serves both ends of the range (adaptive_tree.rs:63-80).
 //
 // Two layouts:
-//   U16: d[] as u16, two LANES per dword: byte address = e*128 + 4*(lane>>1), half = lane&1.
-//        32 KiB per wave -> 4 waves (one per SIMD) + staging fit the CU's 160 KiB.  Valid while
-//        every d[] stays < 65536: blocks of <= 65536 symbols with the (unobservable) update
-//        of a block's last symbol skipped.  Lanes 2m and 2m+1 share a bank (2-way conflict on
-//        differing rows); LDS cycles are not what bounds this kernel.
+//   U16: d[] as u16, two LANES per dword: byte address = e*128 + 4*(lane&31), half = lane>>5.
+//        32 KiB per 64 blocks -> four groups of 64 blocks per CU.  Valid while every d[] stays
+//        < 65536: blocks of <= 65536 symbols with the (unobservable) update of a block's last
+//        symbol skipped.
 //   U32: d[] as u32, byte address = e*256 + 4*lane.  64 KiB per wave; any block length.
 // --------------------------------------------------------------------------------------
 template <bool U16>
@@ -63,12 +62,20 @@ struct Tree {
     uint32_t  inc;  // +1 in this lane's slot of the dword
     uint32_t  sel;  // U16: v_perm selector picking this lane's halves of two dwords
 
+    // the eight node values of one symbol, possibly still in flight from LDS
+    struct Nodes {
+        uint32_t x[8];
+    };
+
     __device__ __forceinline__ void init(uint32_t *p, uint32_t lane)
     {
         lds = p;
-        L   = U16 ? (lane >> 1) * 4u : lane * 4u;
-        inc = (U16 && (lane & 1)) ? 0x10000u : 1u;
-        sel = (lane & 1) ? 0x07060302u : 0x05040100u;
+        // U16: lanes l and l+32 share a dword.  They belong to different LDS lane groups
+        // ({0-31} and {32-63} are serviced in separate LDS cycles), and inside a group every
+        // lane has its own bank: conflict-free for any per-lane row.
+        L   = U16 ? (lane & 31) * 4u : lane * 4u;
+        inc = (U16 && (lane >> 5)) ? 0x10000u : 1u;
+        sel = (lane >> 5) ? 0x07060302u : 0x05040100u;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             A[b] = (1u << (b + kShift)) | L;
@@ -81,10 +88,11 @@ struct Tree {
     {
         return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + byte_addr);
     }
-    __device__ __forceinline__ void add(uint32_t byte_addr, uint32_t v) const
+    // returns the value BEFORE the add: one LDS op serves the query and the update
+    __device__ __forceinline__ uint32_t add(uint32_t byte_addr, uint32_t v) const
     {
-        __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + byte_addr), v,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + byte_addr), v,
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // node address for level b of symbol s: one v_and_or_b32
     __device__ __forceinline__ uint32_t addr(uint32_t ss, int b) const
@@ -98,28 +106,30 @@ struct Tree {
         return U16 ? ((inc == 1u) ? (w & 0xFFFFu) : (w >> 16)) : w;
     }
 
-    // get_frequency(s) of adaptive_tree.rs:105-113 for a byte s: (low, high) of the range
-    // query, then -- if upd -- update(s+1).  d256 = number of updates so far.
-    // The update is eight unconditional ds_add_u32 whose addend is this lane's +1 or 0:
-    // node address > symbol address  <=>  e_b > s  <=>  bit b of s is clear.
+    // First half of get_frequency(s) (adaptive_tree.rs:105-113): touch the eight nodes.
+    // UPD: each level is ONE ds_add_rtn_u32 whose addend is this lane's +1 where update(s+1)
+    // increments the node (node address > symbol address <=> e_b > s <=> bit b of s clear)
+    // and 0 where the prefix sums only read it; the returned pre-add value is the query's.
+    // Splitting issue() from finish() lets the caller put the next symbol's LDS traffic in
+    // flight before it consumes this symbol's values.
     template <bool UPD>
-    __device__ __forceinline__ void get_frequency(uint32_t s, uint32_t d256, bool upd, uint32_t &lo,
-                                                  uint32_t &hi) const
+    __device__ __forceinline__ Nodes issue(uint32_t s, bool upd) const
     {
         const uint32_t ss = s << kShift;
-        uint32_t       a[8], x[8];
+        const uint32_t sa = ss | L;
+        const uint32_t iv = upd ? inc : 0u;
+        Nodes          n;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            a[b] = addr(ss, b);
-            x[b] = ld(a[b]);
+            const uint32_t a = addr(ss, b);
+            n.x[b]           = UPD ? add(a, a > sa ? iv : 0u) : ld(a);
         }
-        if (UPD) {
-            const uint32_t sa = ss | L;
-            const uint32_t iv = upd ? inc : 0u;
-#pragma unroll
-            for (int b = 0; b < 8; b++)
-                add(a[b], a[b] > sa ? iv : 0u);
-        }
+        return n;
+    }
+    // Second half: (low, high) of get_frequency_range(s).  d256 = number of updates so far.
+    __device__ __forceinline__ void finish(uint32_t s, uint32_t d256, const Nodes &n, uint32_t &lo,
+                                           uint32_t &hi) const
+    {
         const uint32_t m  = s + 1;
         uint32_t       ls = s, hs = m;
         if (U16) {
@@ -128,7 +138,7 @@ struct Tree {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // [lo16 = this lane's d[e_2j], hi16 = this lane's d[e_2j+1]]
-                const u16x2 pv  = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(x[2 * j + 1], x[2 * j], sel));
+                const u16x2 pv  = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(n.x[2 * j + 1], n.x[2 * j], sel));
                 const u16x2 sh  = {(uint16_t)(2 * j), (uint16_t)(2 * j + 1)};
                 const u16x2 one = {1, 1};
                 ls = __builtin_amdgcn_udot2(pv, (sv >> sh) & one, ls, false);
@@ -137,12 +147,61 @@ struct Tree {
         } else {
 #pragma unroll
             for (int b = 0; b < 8; b++) {
-                ls += ((s >> b) & 1u) ? x[b] : 0u;
-                hs += ((m >> b) & 1u) ? x[b] : 0u;
+                ls += ((s >> b) & 1u) ? n.x[b] : 0u;
+                hs += ((m >> b) & 1u) ? n.x[b] : 0u;
             }
         }
         lo = ls;
         hi = hs + (m >> 8) * d256; // bit 8 of s+1 selects the derived node 256
+    }
+    template <bool UPD>
+    __device__ __forceinline__ void get_frequency(uint32_t s, uint32_t d256, bool upd, uint32_t &lo,
+                                                  uint32_t &hi) const
+    {
+        const Nodes n = issue<UPD>(s, upd);
+        finish(s, d256, n, lo, hi);
+    }
+
+    // ---- the same two halves restricted to tree levels [4*H, 4*H+4) -------------------
+    // Levels own disjoint nodes, so two waves can each run four levels of every symbol
+    // concurrently; the partial sums add up to finish()'s (lo, hi).  Half 0 carries the
+    // constant terms (s and s+1), half 1 the derived node 256.
+    struct Nodes4 {
+        uint32_t x[4];
+    };
+    template <bool UPD, int H>
+    __device__ __forceinline__ Nodes4 issue4(uint32_t s) const
+    {
+        const uint32_t ss = s << kShift;
+        const uint32_t sa = ss | L;
+        Nodes4         n;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t a = addr(ss, 4 * H + b);
+            n.x[b]           = UPD ? add(a, a > sa ? inc : 0u) : ld(a);
+        }
+        return n;
+    }
+    template <int H>
+    __device__ __forceinline__ void finish4(uint32_t s, uint32_t d256, const Nodes4 &n, uint32_t &lo,
+                                            uint32_t &hi) const
+    {
+        static_assert(U16, "level-split model waves use the u16 tree");
+        const uint32_t m  = s + 1;
+        const u16x2    sv = __builtin_bit_cast(u16x2, s * 0x10001u);
+        const u16x2    mv = __builtin_bit_cast(u16x2, m * 0x10001u);
+        uint32_t       ls = H == 0 ? s : 0u;
+        uint32_t       hs = H == 0 ? m : (m >> 8) * d256;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const u16x2 pv  = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(n.x[2 * j + 1], n.x[2 * j], sel));
+            const u16x2 sh  = {(uint16_t)(4 * H + 2 * j), (uint16_t)(4 * H + 2 * j + 1)};
+            const u16x2 one = {1, 1};
+            ls = __builtin_amdgcn_udot2(pv, (sv >> sh) & one, ls, false);
+            hs = __builtin_amdgcn_udot2(pv, (mv >> sh) & one, hs, false);
+        }
+        lo = ls;
+        hi = hs;
     }
 };
 
@@ -291,6 +350,9 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(m > 32) == 0, 1)) {
         S.acc = (S.acc << m) | (topk + (((1u << Pz) - 1u) << ((k - 1u) & 31u)));
         const uint32_t nb = S.nb + m;
+#ifndef REDUX_SPECULATIVE_STORE
+        if (nb >= 32)
+#endif
         *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> ((nb - 32u) & 63u)));
         S.off += (nb >> 5) << 2;
         S.nb = nb & 31u;

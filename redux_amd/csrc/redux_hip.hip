@@ -220,7 +220,10 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
 //   wave 0: input bytes -> get_frequency -> (low, high) pairs into an LDS ring
 //   wave 1: ring -> interval narrowing, renormalisation, bit output
 // Eight waves per CU = two per SIMD, so each SIMD always has a second instruction stream to
-// issue from.  The ring holds 2 x 8 symbols x 64 lanes x 8 B = 8 KiB (40 KiB per workgroup,
+// issue from.  (Measured, profiles/r01_ubench: a gfx950 SIMD retires the VOP3-type ops this
+// code is made of at ~4.5 cycles per wave-instruction however many waves feed it, so the two
+// streams together run at the SIMD's VALU rate; a third wave -- the model split by tree
+// level -- was built and measured 35 % SLOWER, and was removed.)  The ring holds 2 x 8 symbols x 64 lanes x 8 B = 8 KiB (40 KiB per workgroup,
 // four workgroups = the CU's 160 KiB exactly); one s_barrier per 8 symbols hands a half over.
 // Only LDS traffic must be complete at the hand-off, so the barrier waits on lgkmcnt alone:
 // the coder's stores and the model's prefetch loads stay in flight across it.
@@ -238,15 +241,24 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
                                             uint32_t p, uint32_t nfreeze)
 {
     const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+    // software pipeline: symbol i+1's LDS ops are in flight while symbol i's sums are formed
+    Tree<true>::Nodes nc = T.template issue<UPD>(w[0] & 0xFFu, true);
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const uint32_t s   = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
         const uint32_t nup = UPD ? p + i : nfreeze;
-        uint32_t       lo, hi;
-        T.template get_frequency<UPD>(s, nup, true, lo, hi);
+        Tree<true>::Nodes nn;
+        if (i + 1 < 16) {
+            nn = T.template issue<UPD>((w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu, true);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t lo, hi;
+        T.finish(s, nup, nc, lo, hi);
         ring[i * 64 + lane] = make_uint2(lo, hi);
         if ((i & 7) == 7)
             pair_barrier();
+        if (i + 1 < 16)
+            nc = nn;
     }
 }
 
@@ -260,12 +272,17 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
     for (int i = 0; i < 16; i++)
         r[i] = rc[MODE == 0 ? p + i : nfreeze];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if ((i & 7) == 0)
-            pair_barrier();
-        const uint2    lh  = ring[i * 64 + lane];
-        const uint32_t nup = MODE == 0 ? p + i : nfreeze;
-        encode_symbol_fast<FIXUP>(S, lh.x, lh.y, 257u + nup, r[i], sh, wdst);
+    for (int h = 0; h < 2; h++) {
+        pair_barrier();
+        uint2 lh[8]; // the whole half at once: one LDS round trip per 8 symbols
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            lh[i] = ring[(h * 8 + i) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
+            encode_symbol_fast<FIXUP>(S, lh[i].x, lh[i].y, 257u + nup, r[h * 8 + i], sh, wdst);
+        }
     }
 }
 
@@ -982,7 +999,8 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     // otherwise (giant blocks, whole-stream mode) one block per wave.
     a.lanes = (64ull * g.slot_bytes < (1ull << 32) && 64ull * block_size < (1ull << 32)) ? 64u : 1u;
     const uint32_t grid = (uint32_t)((g.nblocks + a.lanes - 1) / a.lanes);
-    const char *force = getenv("REDUX_ENCODE_KERNEL"); // "single" pins the one-wave kernel (A/B timing only)
+    // REDUX_ENCODE_KERNEL=single pins the one-wave kernel (A/B timing only)
+    const char *force = getenv("REDUX_ENCODE_KERNEL");
     const bool  pair  = g.u16 && a.aligned16 && a.lanes == 64 && !(force && !strcmp(force, "single"));
     if (pair && !g.fixup)
         k_encode_pair<false><<<grid, 128, 0, s>>>(a);

@@ -1,0 +1,179 @@
+// Micro-benchmarks of the instructions the coder's hot loops are made of (gfx950).
+// One 64-thread workgroup with 32 KiB of LDS per wave (4 waves/CU = 1 per SIMD) or
+// 128-thread workgroups with 40 KiB (8 waves/CU = 2 per SIMD), like the real kernels.
+// Prints cycles per wave-instruction assuming the clock reported by hipDeviceProp.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+#include <string>
+
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+#define ITER 4096
+
+template <int T>
+__global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed, unsigned long long *clk)
+{
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    extern __shared__ uint32_t lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *my = lds; (void)wave;   // all waves of the workgroup share one 32 KiB region
+    for (uint32_t i = lane; i < 8192; i += 64) my[i] = i * seed;
+    __syncthreads();
+    uint32_t a[8], x[8];
+    const uint32_t col = (T == 4) ? (lane & 31) * 4 : lane * 4;        // T4: two lanes per dword (l, l+32)
+    const uint32_t col2 = (lane >> 1) * 4;                             // 2-way conflict layout
+#pragma unroll
+    for (int b = 0; b < 8; b++) { a[b] = ((seed * (b + 3) + lane * 7 + b * 11) & 127) * 128 + ((T == 15) ? col2 : (col & 127)); x[b] = seed + b + lane; }
+    double d0 = seed * 1.5, d1 = 0.001 * lane, d2 = 3.0;
+    uint64_t q = seed * 77ull + lane;
+    for (int it = 0; it < ITER; it++) {
+        if (T == 1) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) x[b] += *(volatile uint32_t *)((char *)my + a[b]);
+        } else if (T == 2 || T == 15) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) __hip_atomic_fetch_add((uint32_t *)((char *)my + a[b]), x[b] & 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (T == 3 || T == 4) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) x[b] += __hip_atomic_fetch_add((uint32_t *)((char *)my + a[b]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (T == 5) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x[b]) : "s"(seed), "v"(a[b]));
+        } else if (T == 6) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(x[b]) : "v"(a[b]), "v"(a[(b + 1) & 7]));
+        } else if (T == 7) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_pk_lshrrev_b16 %0, %1, %0" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 8) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x[b]) : "v"(a[b]), "v"(a[(b + 1) & 7]));
+        } else if (T == 9) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) asm volatile("v_cmp_gt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %1, vcc" : "+v"(x[b]) : "v"(a[b]), "v"(a[(b + 1) & 7]) : "vcc");
+        } else if (T == 10) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double t0, t1; uint32_t u;
+                asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(t0) : "v"(x[r]));
+                asm volatile("v_fma_f64 %0, %1, %2, %2" : "=v"(t1) : "v"(t0), "v"(d1));
+                asm volatile("v_mul_f64 %0, %1, %2" : "=v"(t0) : "v"(t1), "v"(d2));
+                asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(u) : "v"(t0));
+                x[r + 4] ^= u;
+            }
+        } else if (T == 11) {
+#pragma unroll
+            for (int b = 0; b < 16; b++) asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(q) : "v"(a[b & 7]));
+        } else if (T == 12) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 13) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) *(volatile uint64_t *)((char *)my + ((a[b] & ~7u))) = ((uint64_t)x[b] << 32) | x[b];
+        } else if (T == 14) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_ffbh_u32 %0, %0" : "+v"(x[b]));
+        } else if (T == 16) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 17) { // dependent chain of adds
+#pragma unroll
+            for (int b = 0; b < 16; b++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[0]) : "v"(a[b & 7]));
+        } else if (T == 18) { // dependent f64 chain
+#pragma unroll
+            for (int b = 0; b < 8; b++) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d0) : "v"(d1));
+        } else if (T == 19) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 20) { // SALU
+#pragma unroll
+            for (int b = 0; b < 16; b++) asm volatile("s_add_u32 %0, %0, 3" : "+s"(seed));
+        }
+    }
+    uint32_t r = (uint32_t)q + (uint32_t)d0 + seed;
+#pragma unroll
+    for (int b = 0; b < 8; b++) r += x[b];
+    out[blockIdx.x * blockDim.x + tid] = r;
+    if (blockIdx.x == 500 && tid == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
+}
+
+template <int T>
+static void run(const char *name, int nper, int threads, size_t lds_bytes, double ghz)
+{
+    uint32_t *out; unsigned long long *clk, hclk[2];
+    hipMalloc(&out, 4096 * 256 * 4); hipMalloc(&clk, 16);
+    hipFuncSetAttribute((const void *)k<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    const int grid = 1024;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k<T><<<grid, threads, lds_bytes>>>(out, 12345, clk);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<T><<<grid, threads, lds_bytes>>>(out, 12345, clk);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(hclk, clk, 16, hipMemcpyDeviceToHost);
+    double real_ghz = (double)hclk[0] / (double)hclk[1] * 0.1; (void)ghz;
+    double cyc = ms * 1e-3 * real_ghz * 1e9 / ITER;
+    printf("%-34s w/SIMD=%d %7.3f ms  clk %.2f GHz  %7.1f cyc/iter  %6.2f cyc/instr/wave  %5.2f cyc/instr/SIMD\n", name, threads / 64, ms, real_ghz, cyc, cyc / nper, cyc / nper / (threads / 64));
+    hipFree(out);
+}
+
+__global__ void kclk(unsigned long long *o) {
+    unsigned long long c0 = clock64(), w0 = wall_clock64();
+    while (wall_clock64() - w0 < 2000000ull) { }   // 20 ms at 100 MHz
+    o[0] = clock64() - c0; o[1] = wall_clock64() - w0;
+}
+int main()
+{
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    unsigned long long *dc, hc[2]; hipMalloc(&dc, 16);
+    kclk<<<1, 64>>>(dc); hipMemcpy(hc, dc, 16, hipMemcpyDeviceToHost);
+    double ghz = (double)hc[0] / (double)hc[1] * 0.1;
+    printf("measured shader clock (idle chip): %.3f GHz; hipDeviceProp clockRate %.2f GHz\n", ghz, p.clockRate / 1e6);
+    printf("device %s clock %.2f GHz CUs %d\n", p.name, ghz, p.multiProcessorCount);
+    for (int cfg = 0; cfg < 4; cfg++) {
+        int th = cfg == 0 ? 64 : cfg == 1 ? 128 : cfg == 2 ? 192 : 256; size_t l = 40960; // 4 workgroups per CU by LDS
+        printf("---- %d wave(s) per workgroup x 4 workgroups per CU = %d waves/SIMD\n", th / 64, th / 64);
+        run<0>("empty loop", 1, th, l, ghz);
+        run<1>("8x ds_read_b32", 8, th, l, ghz);
+        run<2>("8x ds_add_u32", 8, th, l, ghz);
+        run<15>("8x ds_add_u32 2-way conflict", 8, th, l, ghz);
+        run<3>("8x ds_add_rtn_u32", 8, th, l, ghz);
+        run<4>("8x ds_add_rtn_u32 (l,l+32 share)", 8, th, l, ghz);
+        run<13>("8x ds_write_b64", 8, th, l, ghz);
+        run<16>("16x v_add_u32 indep", 16, th, l, ghz);
+        run<17>("16x v_add_u32 dependent", 16, th, l, ghz);
+        run<5>("16x v_and_or_b32", 16, th, l, ghz);
+        run<6>("16x v_dot2_u32_u16", 16, th, l, ghz);
+        run<7>("16x v_pk_lshrrev_b16", 16, th, l, ghz);
+        run<8>("16x v_perm_b32", 16, th, l, ghz);
+        run<9>("8x v_cmp+v_cndmask", 16, th, l, ghz);
+        run<10>("4x (cvt,fma,mul,cvt) f64", 16, th, l, ghz);
+        run<18>("8x v_fma_f64 dependent", 8, th, l, ghz);
+        run<11>("16x v_lshlrev_b64 dependent", 16, th, l, ghz);
+        run<12>("16x v_mul_u32_u24", 16, th, l, ghz);
+        run<19>("16x v_mul_lo_u32", 16, th, l, ghz);
+        run<14>("16x v_ffbh_u32", 16, th, l, ghz);
+        run<20>("16x s_add_u32 dependent", 16, th, l, ghz);
+    }
+    return 0;
+}
