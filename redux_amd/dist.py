@@ -1,0 +1,175 @@
+"""Sharding the block path over the GPUs of one node (one process per GPU, torch.distributed).
+
+Blocks are independent (fresh Codec + fresh model per block: the reference has no
+inter-stream state, src/lib.rs:102-109), so the only communication is moving bytes to and
+from the rank that owns the file:
+
+  synthetic / already-distributed input   no collective at all: every rank codes its own
+                                          contiguous range (bench.py)
+  whole-file runs (BASELINE configs[3])   one scatter of contiguous block ranges from the root
+                                          (the root's xGMI links carry 1/world of the file
+                                          each, in parallel), one all-gather of the per-block
+                                          sizes, one gather of the compressed ranges
+
+`encode_local` / `decode_local` do the actual coding on this rank's device; production passes
+the DeviceEncoder/DeviceDecoder wrappers below, the CPU tests (gloo, world_size 2) inject the
+oracle.  Backend "nccl" is RCCL on ROCm.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def shard_ranges(nblocks, world):
+    """Contiguous block ranges, ceil(nblocks/world) per rank (the last ones may be empty)."""
+    per = math.ceil(nblocks / world) if nblocks else 0
+    return [(min(r * per, nblocks), min((r + 1) * per, nblocks)) for r in range(world)]
+
+
+def block_count(nbytes, block_size):
+    return 1 if nbytes == 0 else (nbytes + block_size - 1) // block_size
+
+
+def _world(group):
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def encode_file_sharded(data, block_size, encode_local, device, group=None, root=0):
+    """Root passes the file as a uint8 tensor on `device` (other ranks pass None).
+    encode_local(uint8 tensor, block_size) -> (dense uint8 tensor, int64 offsets[nb+1]) on `device`.
+    Returns (dense streams, int64 offsets[nblocks+1]) on the root, (None, None) elsewhere."""
+    rank, world = _world(group)
+    hdr = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == root:
+        hdr[0] = data.numel()
+    dist.broadcast(hdr, src=root, group=group)
+    n = int(hdr.item())
+    nblocks = block_count(n, block_size)
+    ranges = shard_ranges(nblocks, world)
+    per = max(b1 - b0 for b0, b1 in ranges)
+    # 1. scatter equal-size (padded) contiguous ranges
+    mine = torch.empty(per * block_size, dtype=torch.uint8, device=device)
+    if rank == root:
+        pad = torch.zeros(world * per * block_size, dtype=torch.uint8, device=device)
+        pad[:n] = data
+        chunks = list(pad.view(world, per * block_size).unbind(0))
+        dist.scatter(mine, chunks, src=root, group=group)
+    else:
+        dist.scatter(mine, None, src=root, group=group)
+    b0, b1 = ranges[rank]
+    my_bytes = max(0, min(n, b1 * block_size) - b0 * block_size) if b1 > b0 else 0
+    if n == 0 and rank == root:
+        b0, b1, my_bytes = 0, 1, 0  # the empty input is one empty block
+    # 2. code this rank's range
+    sizes = torch.zeros(per, dtype=torch.int64, device=device)
+    if b1 > b0:
+        out, offs = encode_local(mine[:my_bytes], block_size)
+        sizes[: b1 - b0] = offs[1:] - offs[:-1]
+        total = int(offs[-1].item())
+    else:
+        out, total = torch.empty(0, dtype=torch.uint8, device=device), 0
+    # 3. per-block sizes to everyone (the root needs them all; the max payload pads step 4)
+    all_sizes = [torch.empty_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    totals = [int(s.sum().item()) for s in all_sizes]
+    cap = max(totals) if totals else 0
+    # 4. gather the compressed ranges (padded to the largest)
+    payload = torch.zeros(max(cap, 1), dtype=torch.uint8, device=device)
+    payload[:total] = out[:total]
+    if rank == root:
+        recv = [torch.empty_like(payload) for _ in range(world)]
+        dist.gather(payload, recv, dst=root, group=group)
+        dense = torch.cat([recv[r][: totals[r]] for r in range(world)])
+        flat = torch.cat([all_sizes[r][: ranges[r][1] - ranges[r][0]] for r in range(world)])
+        if n == 0:
+            flat = all_sizes[root][:1]
+        offsets = torch.zeros(flat.numel() + 1, dtype=torch.int64, device=device)
+        offsets[1:] = torch.cumsum(flat, 0)
+        return dense, offsets
+    dist.gather(payload, None, dst=root, group=group)
+    return None, None
+
+
+def decode_file_sharded(dense, offsets, block_size, decode_local, device, group=None, root=0):
+    """Inverse of encode_file_sharded.  decode_local(dense uint8, int64 offsets[nb+1], block_size)
+    -> (uint8[nb*block_size], int64 sizes[nb]).  Returns the decoded file on the root."""
+    rank, world = _world(group)
+    hdr = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == root:
+        hdr[0] = offsets.numel() - 1
+    dist.broadcast(hdr, src=root, group=group)
+    nblocks = int(hdr.item())
+    ranges = shard_ranges(nblocks, world)
+    per = max(b1 - b0 for b0, b1 in ranges)
+    # sizes to everyone, then padded compressed ranges from the root
+    sizes = torch.zeros(world * per, dtype=torch.int64, device=device)
+    if rank == root:
+        s = offsets[1:] - offsets[:-1]
+        for r, (b0, b1) in enumerate(ranges):
+            sizes[r * per: r * per + (b1 - b0)] = s[b0:b1]
+    dist.broadcast(sizes, src=root, group=group)
+    totals = sizes.view(world, per).sum(1).tolist()
+    cap = max(int(max(totals)), 1)
+    mine = torch.empty(cap, dtype=torch.uint8, device=device)
+    if rank == root:
+        chunks = []
+        for r, (b0, b1) in enumerate(ranges):
+            c = torch.zeros(cap, dtype=torch.uint8, device=device)
+            c[: int(totals[r])] = dense[int(offsets[b0].item()): int(offsets[b1].item())]
+            chunks.append(c)
+        dist.scatter(mine, chunks, src=root, group=group)
+    else:
+        dist.scatter(mine, None, src=root, group=group)
+    b0, b1 = ranges[rank]
+    out = torch.zeros(per * block_size, dtype=torch.uint8, device=device)
+    osz = torch.zeros(per, dtype=torch.int64, device=device)
+    if b1 > b0:
+        my = sizes[rank * per: rank * per + (b1 - b0)]
+        offs = torch.zeros(b1 - b0 + 1, dtype=torch.int64, device=device)
+        offs[1:] = torch.cumsum(my, 0)
+        dec, dsz = decode_local(mine[: int(offs[-1].item())], offs, block_size)
+        out[: dec.numel()] = dec
+        osz[: b1 - b0] = dsz
+    if rank == root:
+        outs = [torch.empty_like(out) for _ in range(world)]
+        szs = [torch.empty_like(osz) for _ in range(world)]
+        dist.gather(out, outs, dst=root, group=group)
+        dist.gather(osz, szs, dst=root, group=group)
+        parts = []
+        for r, (c0, c1) in enumerate(ranges):
+            for i in range(c1 - c0):
+                parts.append(outs[r][i * block_size: i * block_size + int(szs[r][i].item())])
+        return torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=device)
+    dist.gather(out, None, dst=root, group=group)
+    dist.gather(osz, None, dst=root, group=group)
+    return None
+
+
+# ---- production local coders (HBM-resident, the HIP path) ------------------------------------
+def hip_encode_local(params):
+    from . import api
+
+    def f(t, block_size):
+        enc = api.DeviceEncoder(params, block_size, max(t.numel(), 1), device=str(t.device))
+        out, offs, status, summary = enc.encode(t)
+        torch.cuda.synchronize(t.device)
+        st = summary.tolist()
+        if st[0] != 0:
+            api._raise(st[0])
+        return out[: int(offs[-1].item())].clone(), offs.clone()
+    return f
+
+
+def hip_decode_local(params):
+    from . import api
+
+    def f(dense, offs, block_size):
+        dec = api.DeviceDecoder(params, block_size, offs.numel() - 1, device=str(dense.device))
+        out, sizes, status, summary = dec.decode(dense.contiguous(), offs.contiguous())
+        torch.cuda.synchronize(dense.device)
+        st = summary.tolist()
+        if st[0] != 0:
+            api._raise(st[0])
+        return out.clone(), sizes.to(torch.int64)
+    return f

@@ -104,3 +104,23 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "redux_amd", "does_not_exist.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         api.compress_blocks(b"abc", 65536)
+
+
+def build_host_mirror_test(tmpdir):
+    import subprocess
+    exe = os.path.join(str(tmpdir), "host_mirror_test")
+    libdir = os.path.join(ROOT, "redux_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"),
+                           "-L" + libdir, "-lredux_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_host_mirror_compiles_and_validates(tmp_path):
+    """redux_amd/host/redux.hpp (the C++ mirror of the reference's API) builds against the C ABI
+    with plain g++ and its host-only checks pass (no GPU call)."""
+    import subprocess
+    _lib.lib()
+    exe = build_host_mirror_test(tmp_path)
+    out = subprocess.run([exe, "--no-gpu"], capture_output=True, text=True)
+    assert out.returncode == 0 and "host-side checks ok" in out.stdout, out.stderr

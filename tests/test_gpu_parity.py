@@ -270,3 +270,38 @@ def test_dense_output_too_small_is_reported_not_overrun(rx):
     assert st == 0
     assert enc.summary[0].item() == 4 and enc.summary[1].item() >= 5
     assert bool((small[3 * BLOCK:] == 0xAB).all())
+
+
+def test_cpp_host_mirror_end_to_end(rx, tmp_path):
+    """The C++ mirror of the reference API (redux_amd/host/redux.hpp) through the C ABI on the GPU:
+    doc-test, corpus round trip at three widths, Eof on a truncated stream."""
+    import subprocess
+    from test_abi_cpu import build_host_mirror_test
+    exe = build_host_mirror_test(tmp_path)
+    out = subprocess.run([exe, os.path.join(GOLDEN, "corpora", "canterbury", "alice29.txt")], capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0 and "host mirror ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_sharded_driver_on_gpu_world1(rx):
+    """BASELINE.json configs[3] driver (scatter / code / gather over RCCL) with the HIP local
+    coders, world_size 1 (the only size a one-GPU box can run), on resources/large/bible.txt."""
+    import torch
+    import torch.distributed as dist
+    from redux_amd import dist as rd
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        raw = open(os.path.join(GOLDEN, "corpora", "large", "bible.txt"), "rb").read()
+        data = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+        dense, offs = rd.encode_file_sharded(data, BLOCK, rd.hip_encode_local((8, 30, 32)), "cuda:0")
+        gold = json.load(open(os.path.join(GOLDEN, "blocks.json")))["large/bible.txt"]["8_30_32"]
+        o = offs.cpu().numpy()
+        d = dense.cpu().numpy()
+        assert list(np.diff(o)) == gold["block_sizes"]
+        assert [h64(d[int(o[i]): int(o[i + 1])]) for i in range(len(o) - 1)] == gold["block_hashes"]
+        back = rd.decode_file_sharded(dense, offs, BLOCK, rd.hip_decode_local((8, 30, 32)), "cuda:0")
+        assert back.cpu().numpy().tobytes() == raw
+    finally:
+        dist.destroy_process_group()
