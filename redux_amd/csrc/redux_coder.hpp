@@ -61,6 +61,7 @@ struct Tree {
     uint32_t  L;    // this lane's column (byte offset inside a row)
     uint32_t  inc;  // +1 in this lane's slot of the dword
     uint32_t  sel;  // U16: v_perm selector picking this lane's halves of two dwords
+    uint32_t  hsh;  // U16: bit position of this lane's slot (0 or 16)
 
     // the eight node values of one symbol, possibly still in flight from LDS
     struct Nodes {
@@ -76,6 +77,7 @@ struct Tree {
         L   = U16 ? (lane & 31) * 4u : lane * 4u;
         inc = (U16 && (lane >> 5)) ? 0x10000u : 1u;
         sel = (lane >> 5) ? 0x07060302u : 0x05040100u;
+        hsh = (U16 && (lane >> 5)) ? 16u : 0u;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             A[b] = (1u << (b + kShift)) | L;
@@ -108,51 +110,58 @@ struct Tree {
 
     // First half of get_frequency(s) (adaptive_tree.rs:105-113): touch the eight nodes.
     // UPD: each level is ONE ds_add_rtn_u32 whose addend is this lane's +1 where update(s+1)
-    // increments the node (node address > symbol address <=> e_b > s <=> bit b of s clear)
-    // and 0 where the prefix sums only read it; the returned pre-add value is the query's.
+    // increments the node (bit b of s clear) and 0 where the prefix sums only read it; the
+    // returned pre-add value is the query's.  The addend is ((~s) << slot) >> b & inc: plain
+    // shift + and, which a gfx950 SIMD retires at twice the rate of a compare/select pair
+    // (and without the 2 wait states between a VALU VCC write and its VALU read).
     // Splitting issue() from finish() lets the caller put the next symbol's LDS traffic in
     // flight before it consumes this symbol's values.
     template <bool UPD>
     __device__ __forceinline__ Nodes issue(uint32_t s, bool upd) const
     {
-        const uint32_t ss = s << kShift;
-        const uint32_t sa = ss | L;
-        const uint32_t iv = upd ? inc : 0u;
+        const uint32_t ss  = s << kShift;
+        const uint32_t nsl = (s ^ 0xFFu) << hsh;
+        const uint32_t iv  = upd ? inc : 0u;
         Nodes          n;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             const uint32_t a = addr(ss, b);
-            n.x[b]           = UPD ? add(a, a > sa ? iv : 0u) : ld(a);
+            n.x[b]           = UPD ? add(a, (nsl >> b) & iv) : ld(a);
         }
         return n;
     }
     // Second half: (low, high) of get_frequency_range(s).  d256 = number of updates so far.
+    // u = s * 0x8001 puts bit i of s at bits i and 15+i, so (u >> 2j) & 0x10001 is the pair
+    // (bit 2j, bit 2j+1) in the two 16-bit lanes of a v_dot2_u32_u16 -- one 32-bit shift
+    // instead of a packed shift; for s+1 the same with u + 0x8001.
     __device__ __forceinline__ void finish(uint32_t s, uint32_t d256, const Nodes &n, uint32_t &lo,
                                            uint32_t &hi) const
     {
-        const uint32_t m  = s + 1;
-        uint32_t       ls = s, hs = m;
+        const uint32_t m = s + 1;
         if (U16) {
-            const u16x2 sv = __builtin_bit_cast(u16x2, s * 0x10001u);
-            const u16x2 mv = __builtin_bit_cast(u16x2, m * 0x10001u);
+            const uint32_t us = s * 0x8001u;
+            const uint32_t um = us + 0x8001u;
+            uint32_t       ls = s;
+            uint32_t       hs = (m >> 8) * d256 + m; // bit 8 of s+1 selects the derived node 256
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // [lo16 = this lane's d[e_2j], hi16 = this lane's d[e_2j+1]]
-                const u16x2 pv  = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(n.x[2 * j + 1], n.x[2 * j], sel));
-                const u16x2 sh  = {(uint16_t)(2 * j), (uint16_t)(2 * j + 1)};
-                const u16x2 one = {1, 1};
-                ls = __builtin_amdgcn_udot2(pv, (sv >> sh) & one, ls, false);
-                hs = __builtin_amdgcn_udot2(pv, (mv >> sh) & one, hs, false);
+                const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(n.x[2 * j + 1], n.x[2 * j], sel));
+                ls = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, (us >> (2 * j)) & 0x10001u), ls, false);
+                hs = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, (um >> (2 * j)) & 0x10001u), hs, false);
             }
+            lo = ls;
+            hi = hs;
         } else {
+            uint32_t ls = s, hs = m;
 #pragma unroll
             for (int b = 0; b < 8; b++) {
                 ls += ((s >> b) & 1u) ? n.x[b] : 0u;
                 hs += ((m >> b) & 1u) ? n.x[b] : 0u;
             }
+            lo = ls;
+            hi = hs + (m >> 8) * d256;
         }
-        lo = ls;
-        hi = hs + (m >> 8) * d256; // bit 8 of s+1 selects the derived node 256
     }
     template <bool UPD>
     __device__ __forceinline__ void get_frequency(uint32_t s, uint32_t d256, bool upd, uint32_t &lo,
@@ -160,48 +169,6 @@ struct Tree {
     {
         const Nodes n = issue<UPD>(s, upd);
         finish(s, d256, n, lo, hi);
-    }
-
-    // ---- the same two halves restricted to tree levels [4*H, 4*H+4) -------------------
-    // Levels own disjoint nodes, so two waves can each run four levels of every symbol
-    // concurrently; the partial sums add up to finish()'s (lo, hi).  Half 0 carries the
-    // constant terms (s and s+1), half 1 the derived node 256.
-    struct Nodes4 {
-        uint32_t x[4];
-    };
-    template <bool UPD, int H>
-    __device__ __forceinline__ Nodes4 issue4(uint32_t s) const
-    {
-        const uint32_t ss = s << kShift;
-        const uint32_t sa = ss | L;
-        Nodes4         n;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const uint32_t a = addr(ss, 4 * H + b);
-            n.x[b]           = UPD ? add(a, a > sa ? inc : 0u) : ld(a);
-        }
-        return n;
-    }
-    template <int H>
-    __device__ __forceinline__ void finish4(uint32_t s, uint32_t d256, const Nodes4 &n, uint32_t &lo,
-                                            uint32_t &hi) const
-    {
-        static_assert(U16, "level-split model waves use the u16 tree");
-        const uint32_t m  = s + 1;
-        const u16x2    sv = __builtin_bit_cast(u16x2, s * 0x10001u);
-        const u16x2    mv = __builtin_bit_cast(u16x2, m * 0x10001u);
-        uint32_t       ls = H == 0 ? s : 0u;
-        uint32_t       hs = H == 0 ? m : (m >> 8) * d256;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const u16x2 pv  = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(n.x[2 * j + 1], n.x[2 * j], sel));
-            const u16x2 sh  = {(uint16_t)(4 * H + 2 * j), (uint16_t)(4 * H + 2 * j + 1)};
-            const u16x2 one = {1, 1};
-            ls = __builtin_amdgcn_udot2(pv, (sv >> sh) & one, ls, false);
-            hs = __builtin_amdgcn_udot2(pv, (mv >> sh) & one, hs, false);
-        }
-        lo = ls;
-        hi = hs;
     }
 };
 
@@ -330,10 +297,16 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
     const uint32_t R1 = (~(S.ihigh + S.low)) >> sh;
     const double   Y  = __builtin_fma((double)R1, rc, rc);
     const uint32_t nlow   = S.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
-    const uint32_t nihigh = ~(S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh) - 1u);
+    const uint32_t nihigh = 0u - (S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh)); // ~(new high) = -(high + 1)
 
+    // k = clz(low ^ high) through v_ffbh_u32, which returns -1 for low == high (k = 32).
+    // Masked to 6 bits that is 63: the 64-bit shifts then shift everything out exactly as
+    // k = 32 would, so the state update needs no clamp (v_min is a half-rate op here); the
+    // emission sees k + P > 32 and takes the careful path, which uses the clamped k.
     const uint32_t x    = ~(nlow ^ nihigh);
-    const uint32_t k    = x ? (uint32_t)__builtin_clz(x) : 32u;
+    uint32_t       kraw;
+    asm("v_ffbh_u32 %0, %1" : "=v"(kraw) : "v"(x));
+    const uint32_t k    = kraw & 63u; // 0..31, or 63 for low == high
     const uint64_t sl   = (uint64_t)nlow << k;
     const uint32_t topk = (uint32_t)(sl >> 32);
     const uint32_t low2 = (uint32_t)sl;
@@ -353,17 +326,26 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
 #ifndef REDUX_SPECULATIVE_STORE
         if (nb >= 32)
 #endif
-        *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> ((nb - 32u) & 63u)));
+        {
+            *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> ((nb - 32u) & 63u)));
+#ifndef REDUX_SPECULATIVE_STORE
+            S.off += 4;
+#endif
+        }
+#ifdef REDUX_SPECULATIVE_STORE
         S.off += (nb >> 5) << 2;
+#endif
         S.nb = nb & 31u;
-    } else { // some lane has a pending run too long for one append: careful path for all
-        if (m <= 32) {
-            put_bits(S, topk + (((1u << Pz) - 1u) << ((k - 1u) & 31u)), m, wbase, 0xFFFFFFFFu);
+    } else { // some lane has a pending run too long for one append (or k = 32): careful path for all
+        const uint32_t kk = k > 32 ? 32u : k;
+        const uint32_t tk = k > 32 ? nlow : topk;
+        if (kk + Pz <= 32) {
+            put_bits(S, tk + (((1u << Pz) - 1u) << ((kk - 1u) & 31u)), kk + Pz, wbase, 0xFFFFFFFFu);
         } else {
-            const uint32_t b = topk >> (k - 1);
+            const uint32_t b = tk >> (kk - 1);
             put_bits(S, b, 1, wbase, 0xFFFFFFFFu);
             put_run(S, b ^ 1u, P, wbase, 0xFFFFFFFFu);
-            put_bits(S, topk & ((1u << (k - 1)) - 1u), k - 1, wbase, 0xFFFFFFFFu);
+            put_bits(S, tk & ((1u << (kk - 1)) - 1u), kk - 1, wbase, 0xFFFFFFFFu);
         }
     }
 }

@@ -102,6 +102,158 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed, unsigned 
             for (int r = 0; r < 2; r++)
 #pragma unroll
                 for (int b = 0; b < 8; b++) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+} else if (T == 30) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 31) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_or_b32 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 32) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 33) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 34) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 35) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 36) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 37) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_bfe_u32 %0, %0, %1, 8" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 38) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 39) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 40) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_not_b32 %0, %0" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 41) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_mov_b32 %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 42) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 43) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 44) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 45) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 46) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 47) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[b]) : "v"(a[b]) : "vcc");
+        } else if (T == 48) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_cmp_gt_u32 vcc, %0, %1" : "+v"(x[b]) : "v"(a[b]) : "vcc");
+        } else if (T == 49) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 50) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_bfm_b32 %0, %0, %1" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 51) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 52) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_sub_u32 %0, 32, %0" : "+v"(x[b]) : "v"(a[b]));
+        } else if (T == 53) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(x[b]) : "v"(a[b]) : "vcc");
+} else if (T == 60) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) { double t; asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(t) : "v"(x[b])); asm volatile("" :: "v"(t)); }
+        } else if (T == 61) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) { double t; asm volatile("v_mul_f64 %0, %1, %2" : "=v"(t) : "v"(d1), "v"(d2)); asm volatile("" :: "v"(t)); }
+        } else if (T == 62) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) { double t; asm volatile("v_fma_f64 %0, %1, %2, %2" : "=v"(t) : "v"(d1), "v"(d2)); asm volatile("" :: "v"(t)); }
+        } else if (T == 63) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) { uint32_t t; asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(t) : "v"(d1)); asm volatile("" :: "v"(t)); }
+        } else if (T == 64) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) { uint64_t t; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(t) : "v"(x[b]), "v"(a[b]), "v"(q) : "vcc"); asm volatile("" :: "v"(t)); }
+        } else if (T == 65) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) { uint64_t t; asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(t) : "v"(a[b]), "v"(q)); asm volatile("" :: "v"(t)); }
+        } else if (T == 66) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) { float t; asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(t) : "v"(x[b])); asm volatile("" :: "v"(t)); }
+        } else if (T == 67) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) { uint2 t; asm volatile("ds_read_b64 %0, %1" : "=v"(t) : "v"(a[b] & ~7u)); asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(t)); }
+        } else if (T == 68) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) { asm volatile("ds_write_b64 %0, %1" :: "v"(a[b] & ~7u), "v"(q)); }
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (T == 69) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) { uint32_t t; asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"(a[b])); asm volatile("" :: "v"(t)); }
+            asm volatile("s_waitcnt lgkmcnt(0)");
         } else if (T == 20) { // SALU
 #pragma unroll
             for (int b = 0; b < 16; b++) asm volatile("s_add_u32 %0, %0, 3" : "+s"(seed));
@@ -150,7 +302,7 @@ int main()
     double ghz = (double)hc[0] / (double)hc[1] * 0.1;
     printf("measured shader clock (idle chip): %.3f GHz; hipDeviceProp clockRate %.2f GHz\n", ghz, p.clockRate / 1e6);
     printf("device %s clock %.2f GHz CUs %d\n", p.name, ghz, p.multiProcessorCount);
-    for (int cfg = 0; cfg < 4; cfg++) {
+    for (int cfg = 0; cfg < 2; cfg++) {
         int th = cfg == 0 ? 64 : cfg == 1 ? 128 : cfg == 2 ? 192 : 256; size_t l = 40960; // 4 workgroups per CU by LDS
         printf("---- %d wave(s) per workgroup x 4 workgroups per CU = %d waves/SIMD\n", th / 64, th / 64);
         run<0>("empty loop", 1, th, l, ghz);
@@ -173,6 +325,40 @@ int main()
         run<12>("16x v_mul_u32_u24", 16, th, l, ghz);
         run<19>("16x v_mul_lo_u32", 16, th, l, ghz);
         run<14>("16x v_ffbh_u32", 16, th, l, ghz);
+        run<30>("16x v_and_b32 (VOP2)", 16, th, l, ghz);
+        run<31>("16x v_or_b32 (VOP2)", 16, th, l, ghz);
+        run<32>("16x v_xor_b32 (VOP2)", 16, th, l, ghz);
+        run<33>("16x v_lshlrev_b32 (VOP2)", 16, th, l, ghz);
+        run<34>("16x v_lshrrev_b32 (VOP2)", 16, th, l, ghz);
+        run<35>("16x v_sub_u32 (VOP2)", 16, th, l, ghz);
+        run<36>("16x v_min_u32 (VOP2)", 16, th, l, ghz);
+        run<37>("16x v_bfe_u32 (VOP3)", 16, th, l, ghz);
+        run<38>("16x v_lshl_add_u32 (VOP3)", 16, th, l, ghz);
+        run<39>("16x v_add3_u32 (VOP3)", 16, th, l, ghz);
+        run<40>("16x v_not_b32 (VOP1)", 16, th, l, ghz);
+        run<41>("16x v_mov_b32 (VOP1)", 16, th, l, ghz);
+        run<42>("16x v_and_b32 SDWA byte sel", 16, th, l, ghz);
+        run<43>("16x v_add_u32 + literal", 16, th, l, ghz);
+        run<44>("16x v_bfi_b32 (VOP3)", 16, th, l, ghz);
+        run<45>("16x v_alignbit_b32 (VOP3)", 16, th, l, ghz);
+        run<46>("16x v_mul_hi_u32 (VOP3)", 16, th, l, ghz);
+        run<47>("16x v_cndmask_b32 (VOP2, vcc)", 16, th, l, ghz);
+        run<48>("16x v_cmp_gt_u32 (VOPC)", 16, th, l, ghz);
+        run<49>("16x v_and_or_b32 all-VGPR", 16, th, l, ghz);
+        run<50>("16x v_bfm_b32 (VOP3)", 16, th, l, ghz);
+        run<51>("16x v_add_u32 DPP", 16, th, l, ghz);
+        run<52>("16x v_sub_u32 inline const", 16, th, l, ghz);
+        run<53>("16x v_addc_co_u32", 16, th, l, ghz);
+        run<60>("8x v_cvt_f64_u32 indep", 8, th, l, ghz);
+        run<61>("8x v_mul_f64 indep", 8, th, l, ghz);
+        run<62>("8x v_fma_f64 indep", 8, th, l, ghz);
+        run<63>("8x v_cvt_u32_f64 indep", 8, th, l, ghz);
+        run<64>("8x v_mad_u64_u32 indep", 8, th, l, ghz);
+        run<65>("8x v_lshlrev_b64 indep", 8, th, l, ghz);
+        run<66>("8x v_cvt_f32_u32 indep", 8, th, l, ghz);
+        run<67>("8x ds_read_b64 (latency each)", 8, th, l, ghz);
+        run<68>("8x ds_write_b64 throughput", 8, th, l, ghz);
+        run<69>("8x ds_read_b32 throughput", 8, th, l, ghz);
         run<20>("16x s_add_u32 dependent", 16, th, l, ghz);
     }
     return 0;
