@@ -305,3 +305,35 @@ def test_sharded_driver_on_gpu_world1(rx):
         assert back.cpu().numpy().tobytes() == raw
     finally:
         dist.destroy_process_group()
+
+
+def _adversarial_cases():
+    import random
+    adv = os.path.join(GOLDEN, "adversarial")
+    rnd = random.Random(77)
+    out = []
+    for f in sorted(os.listdir(adv)):
+        if f.endswith(".bin"):
+            base = open(os.path.join(adv, f), "rb").read()
+            params = tuple(int(x) for x in f[:-4].split("_")[-3:])
+            tail = bytes(rnd.randrange(256) for _ in range(300))
+            out.append((f, params, base))
+            out.append((f + "+tail", params, base + tail))
+    return out
+
+
+@pytest.mark.parametrize("name,params,data", _adversarial_cases())
+def test_adversarial_rare_paths(rx, name, params, data):
+    """Forces the data-dependent rare paths: pending runs of hundreds of bits (flushed at EOF
+    and, with a random tail, inside the unrolled loop) and low == high after narrowing
+    (k = code_bits).  Every lane of a wave gets the input so the wave-level ballots fire."""
+    blocks = data + bytes((-len(data)) % 16)           # 16-byte multiple so that all blocks are equal
+    bs = len(blocks)
+    many = blocks * 5 + data                            # 5 identical full blocks + the exact input as a ragged last one
+    for w in {params, (8, 30, 32)}:
+        out, offs, st = rx.compress_blocks(many, bs, w)
+        want, _ = ox.compress_blocks(many, bs, w, slot=4 * bs + 4096)
+        assert split(out, offs) == want, (name, w)
+        dec, sizes, _ = rx.decompress_blocks(out, offs, bs, w)
+        got = b"".join(dec[b * bs: b * bs + int(sizes[b])].tobytes() for b in range(len(sizes)))
+        assert got == many, (name, w)

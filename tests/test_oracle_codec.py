@@ -117,3 +117,34 @@ def test_truncated_and_overlong_streams():
     assert e.value.status == ox.IO_ERROR
     d, dc = ox.decompress(s + b"\x00\x00junk", (8, 30, 32))  # trailing bytes are never read
     assert d == data and dc[0] == len(s)
+
+
+ADV = os.path.join(GOLDEN, "adversarial")
+
+
+def adversarial_cases():
+    rnd = random.Random(77)
+    out = []
+    for f in sorted(os.listdir(ADV)):
+        if not f.endswith(".bin"):
+            continue
+        base = open(os.path.join(ADV, f), "rb").read()
+        params = tuple(int(x) for x in f[:-4].split("_")[-3:])
+        tail = bytes(rnd.randrange(256) for _ in range(300))
+        out.append((f, params, base))
+        out.append((f + "+tail", params, base + tail))
+    return out
+
+
+@pytest.mark.parametrize("name,params,data", adversarial_cases())
+def test_adversarial_inputs_c_equals_python(name, params, data):
+    """Inputs built to force long pending runs (hundreds of E3 bits) and low == high after
+    narrowing (tests/golden/make_adversarial.py): both restatements agree and round-trip."""
+    d = data[:4000]
+    s, c = ox.compress(d, params, ox.TREE)
+    s2, c2 = rr.compress(d, rr.AdaptiveTreeModel(rr.Parameters(*params)))
+    assert s == s2 and c == c2
+    back, _ = ox.decompress(s, params, ox.TREE, cap=len(d) + 16)
+    assert back == d
+    sl, _ = ox.compress(d, params, ox.LINEAR)
+    assert sl == s
