@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=65536, help="blocks per GPU (default: the config's 65,536)")
     ap.add_argument("--workload", choices=["iid", "zipf"], default="iid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode", action="store_true", help="also time the decode kernel (extra field decode_MBps)")
     ap.add_argument("--cpu-sample-blocks", type=int, default=4096)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: usable cores)")
     args = ap.parse_args()
@@ -175,6 +176,21 @@ def main():
             "kernel_ms": round(kern_ms, 3),
         },
     }
+
+    if args.decode:
+        dec = rx.DeviceDecoder(PARAMS, BLOCK, nblocks, device=dev)
+        offs_t = enc.offsets[: nblocks + 1]
+        dense = enc.out[:out_bytes]
+        dec.decode(dense, offs_t)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        d_out, d_sizes, d_status, d_sum = dec.decode(dense, offs_t)
+        e1.record()
+        torch.cuda.synchronize()
+        assert d_sum.tolist() == [0, 0] and torch.equal(d_out, d_in), "decode(encode(x)) != x"
+        line["decode"] = {"ms": round(e0.elapsed_time(e1), 3), "MBps": round(n / (e0.elapsed_time(e1) * 1e-3) / 1e6, 1),
+                          "roundtrip_equal": True}
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import cbind as ox

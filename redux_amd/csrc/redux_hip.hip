@@ -236,6 +236,67 @@ __device__ __forceinline__ void pair_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Input path of the model wave: every lane reads its own block one whole 128-byte line at a
+// time (eight 16-byte loads issued back to back), so each line crosses the L2 <-> fabric
+// boundary once: FETCH_SIZE 2.14e6 KiB per 4 GiB pass, identical to a clean streaming read,
+// against 7.4e6-9.5e6 KiB with 16 bytes per visit (the line was evicted between visits), and
+// WRITE_SIZE drops 38 % as well (less L2 pollution).  c[] is the current line, n[] the next
+// one, already in flight; the chunk index is wave-uniform (the lanes advance in lock-step),
+// so pop() is a scalar switch.  Costs 2.8 % of kernel time (profiles/r01_traffic_matrix.txt);
+// -DREDUX_NO_LINE_QUEUE restores the 16-byte prefetch for A/B runs.
+struct ChunkQueue {
+    const uint8_t *base; // wave-uniform
+    uint32_t       soff; // this lane's block offset
+    uint32_t       last; // offset of the last 16-byte chunk the unrolled path reads
+    uint32_t       nextp;
+    uint32_t       idx;  // next chunk of c[] (wave-uniform)
+    uint4          c[8], n[8];
+
+    // chunks past the end re-read the last valid chunk (never used)
+    __device__ __forceinline__ void prefetch()
+    {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t p = nextp + 16 * i;
+            n[i] = *reinterpret_cast<const uint4 *>(base + soff + (p < last ? p : last));
+        }
+        nextp += 128;
+    }
+    // current line <- prefetched line, then put the line after it in flight
+    __device__ __forceinline__ void swap()
+    {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            c[i] = n[i];
+        idx = 0;
+        prefetch();
+    }
+    __device__ __forceinline__ void init(const uint8_t *b, uint32_t so, uint32_t e)
+    {
+        base = b; soff = so; last = e - 16; nextp = 0;
+        prefetch();
+        swap();
+    }
+    // the next 16 bytes of every lane's block
+    __device__ __forceinline__ uint4 pop()
+    {
+        uint4 r;
+        switch (idx) {
+        case 0: r = c[0]; break;
+        case 1: r = c[1]; break;
+        case 2: r = c[2]; break;
+        case 3: r = c[3]; break;
+        case 4: r = c[4]; break;
+        case 5: r = c[5]; break;
+        case 6: r = c[6]; break;
+        default: r = c[7]; break;
+        }
+        if (++idx == 8)
+            swap();
+        return r;
+    }
+};
+
 template <bool UPD>
 __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, uint32_t lane, const uint4 cur,
                                             uint32_t p, uint32_t nfreeze)
@@ -350,16 +411,25 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
     if (wave == 0) {
         // ---------------- model wave ----------------
         if (main_end) {
-            uint32_t p   = 0;
-            uint4    cur = *reinterpret_cast<const uint4 *>(wsrc + soff);
-            for (; p < a_end; p += 16) {
-                uint4 nxt = cur;
-                if (p + 16 < main_end)
-                    nxt = *reinterpret_cast<const uint4 *>(wsrc + soff + p + 16);
-                model_chunk<true>(T, ring, lane, cur, p, nfreeze);
-                cur = nxt;
-            }
+            uint32_t p = 0;
+#ifndef REDUX_NO_LINE_QUEUE
+            ChunkQueue Q;
+            Q.init(wsrc, soff, main_end);
+#define NEXT_CHUNK() Q.pop()
+#else
+            uint4 cur = *reinterpret_cast<const uint4 *>(wsrc + soff);
+            auto  next_chunk = [&](uint32_t pp) {
+                const uint4 r = cur;
+                if (pp + 16 < main_end)
+                    cur = *reinterpret_cast<const uint4 *>(wsrc + soff + pp + 16);
+                return r;
+            };
+#define NEXT_CHUNK() next_chunk(p)
+#endif
+            for (; p < a_end; p += 16)
+                model_chunk<true>(T, ring, lane, NEXT_CHUNK(), p, nfreeze);
             for (; p < m_end; p += 16) { // rolled: the update stops in the middle of this chunk
+                (void)NEXT_CHUNK();
                 for (uint32_t i = 0; i < 16; i++) {
                     const uint32_t q   = p + i;
                     const uint32_t nup = q < nfreeze ? q : nfreeze;
@@ -369,16 +439,10 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
                     if ((i & 7) == 7)
                         pair_barrier();
                 }
-                if (p + 16 < main_end)
-                    cur = *reinterpret_cast<const uint4 *>(wsrc + soff + p + 16);
             }
-            for (; p < main_end; p += 16) {
-                uint4 nxt = cur;
-                if (p + 16 < main_end)
-                    nxt = *reinterpret_cast<const uint4 *>(wsrc + soff + p + 16);
-                model_chunk<false>(T, ring, lane, cur, p, nfreeze);
-                cur = nxt;
-            }
+            for (; p < main_end; p += 16)
+                model_chunk<false>(T, ring, lane, NEXT_CHUNK(), p, nfreeze);
+#undef NEXT_CHUNK
         }
     } else {
         // ---------------- coder wave ----------------
@@ -438,25 +502,32 @@ struct DecArgs {
 struct BitIn {
     uint64_t        bits;
     uint32_t        cnt;
+    uint32_t        nextw; // the following dword, already loaded: a refill never waits on memory
     const uint32_t *rp, *end;
 
+    __device__ __forceinline__ uint32_t fetch()
+    {
+        const uint32_t w = rp < end ? *rp : 0u;
+        rp++;
+        return w;
+    }
     __device__ __forceinline__ void refill()
     {
         if (cnt <= 32) {
-            const uint32_t w = rp < end ? __builtin_bswap32(*rp) : 0u;
-            rp++;
-            bits |= (uint64_t)w << (32 - cnt);
+            bits |= (uint64_t)__builtin_bswap32(nextw) << (32 - cnt);
             cnt += 32;
+            nextw = fetch(); // consumed by the NEXT refill of this lane, several symbols from now
         }
     }
     __device__ __forceinline__ void init(const uint8_t *sp, uint64_t size)
     {
         const uintptr_t a = (uintptr_t)sp & ~(uintptr_t)3;
         const uint32_t  skip = (uint32_t)((uintptr_t)sp & 3) * 8;
-        rp   = reinterpret_cast<const uint32_t *>(a);
-        end  = reinterpret_cast<const uint32_t *>(((uintptr_t)sp + size + 3) & ~(uintptr_t)3);
-        bits = 0;
-        cnt  = 0;
+        rp    = reinterpret_cast<const uint32_t *>(a);
+        end   = reinterpret_cast<const uint32_t *>(((uintptr_t)sp + size + 3) & ~(uintptr_t)3);
+        bits  = 0;
+        cnt   = 0;
+        nextw = fetch();
         refill();
         bits <<= skip;
         cnt -= skip;
@@ -893,7 +964,13 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.nblocks = in_len == 0 ? 1 : (in_len + block_size - 1) / block_size;
     const uint64_t cap = slot_cap_for(p, block_size);
     g.slot_cap   = cap > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)cap;
-    g.slot_bytes = align_up((uint64_t)g.slot_cap + 32, 16);
+    // Slot stride: a whole number of 128-byte lines, and an ODD one.  All lanes write their
+    // slots at about the same relative offset, so a stride that is a multiple of 2^k lines
+    // folds the concurrently written lines onto 1/2^k of the L2 sets and evicts them
+    // half-written (measured: 2.6x the stream bytes written to HBM at a stride of 584 lines).
+    g.slot_bytes = align_up((uint64_t)g.slot_cap + 32, 128);
+    if (((g.slot_bytes / 128) & 1) == 0)
+        g.slot_bytes += 128;
     const uint64_t freq_max = (1ull << p->freq_bits) - 1;
     g.nfreeze = (uint32_t)(freq_max - 257);
     const uint64_t maxlen = in_len < block_size ? in_len : block_size;
