@@ -493,6 +493,7 @@ struct DecArgs {
     uint32_t        nfreeze;
     uint32_t        code_bits;
     uint32_t        aligned4;   // out and block_size are 4-byte multiples
+    uint64_t       *in_used;    // optional: bytes of each stream the reader fetched (ByteCount, bitio/mod.rs:71)
 };
 
 // BitReader (bitio/mod.rs:78-120) as a 64-bit look-ahead register: the `cnt` not yet
@@ -699,6 +700,10 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
                 dst[i] = (uint8_t)(obuf >> (8 * (i & 3)));
         a.out_sizes[blk] = n_out;
         a.status[blk]    = st;
+        if (a.in_used) { // the reader fetches whole bytes, and never past the end of the stream
+            const uint64_t used = ((uint64_t)consumed + 7) / 8;
+            a.in_used[blk]      = used < size ? used : size;
+        }
     }
 }
 
@@ -931,6 +936,10 @@ __global__ void __launch_bounds__(64) k_decode_fast(DecArgs a)
                 dst[i] = (uint8_t)(obuf >> (8 * (i & 3)));
         a.out_sizes[blk] = n_out;
         a.status[blk]    = st;
+        if (a.in_used) { // the reader fetches whole bytes, and never past the end of the stream
+            const uint64_t used = ((uint64_t)consumed + 7) / 8;
+            a.in_used[blk]      = used < size ? used : size;
+        }
     }
 }
 
@@ -1448,10 +1457,12 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
     return align_up((uint64_t)g.rc_n * 8, 256);
 }
 
-int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void *d_in_offsets, uint64_t nblocks,
-                            uint32_t block_size, void *d_out, uint64_t out_cap, void *d_out_sizes,
-                            void *d_block_status, void *d_summary, void *d_workspace, uint64_t workspace_bytes,
-                            void *stream)
+// d_in_used (optional, u64[nblocks]): bytes of each stream the reader fetched; only
+// redux_decompress asks for it (the (u64, u64) of src/lib.rs:119)
+static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const void *d_in_offsets, uint64_t nblocks,
+                                  uint32_t block_size, void *d_out, uint64_t out_cap, void *d_out_sizes,
+                                  void *d_block_status, void *d_summary, void *d_workspace,
+                                  uint64_t workspace_bytes, void *stream, void *d_in_used)
 {
     int st = check_params(p);
     if (st != REDUX_OK)
@@ -1479,6 +1490,7 @@ int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void 
     a.nfreeze    = g.nfreeze;
     a.code_bits  = p->code_bits;
     a.aligned4   = ((((uintptr_t)d_out) & 3) == 0 && (block_size & 3) == 0) ? 1 : 0;
+    a.in_used    = (uint64_t *)d_in_used;
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
     const char *force = getenv("REDUX_DECODE_KERNEL"); // "generic" pins k_decode (A/B timing only)
     if (g.u16 && !g.fixup && !(force && !strcmp(force, "generic")))
@@ -1495,9 +1507,18 @@ int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void 
     return REDUX_OK;
 }
 
-int redux_decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
-                        uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes,
-                        int32_t *block_status)
+int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void *d_in_offsets, uint64_t nblocks,
+                            uint32_t block_size, void *d_out, uint64_t out_cap, void *d_out_sizes,
+                            void *d_block_status, void *d_summary, void *d_workspace, uint64_t workspace_bytes,
+                            void *stream)
+{
+    return decode_blocks_dev_impl(p, d_in, d_in_offsets, nblocks, block_size, d_out, out_cap, d_out_sizes,
+                                  d_block_status, d_summary, d_workspace, workspace_bytes, stream, nullptr);
+}
+
+static int decode_blocks_host(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
+                              uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes,
+                              int32_t *block_status, uint64_t *in_used)
 {
     int st = check_params(p);
     if (st != REDUX_OK)
@@ -1513,6 +1534,7 @@ int redux_decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t
     uint8_t  *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr;
     uint64_t *d_off = nullptr;
     uint32_t *d_sz = nullptr;
+    uint64_t *d_used = nullptr;
     int32_t  *d_st = nullptr, *d_sum = nullptr;
     int       rc = REDUX_OK;
     int32_t   summary[2] = {0, 0};
@@ -1532,25 +1554,36 @@ int redux_decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t
     TRY_GOTO(hipMalloc((void **)&d_sz, nblocks * 4));
     TRY_GOTO(hipMalloc((void **)&d_st, nblocks * 4));
     TRY_GOTO(hipMalloc((void **)&d_sum, 8));
+    if (in_used)
+        TRY_GOTO(hipMalloc((void **)&d_used, nblocks * 8));
     if (in_len)
         TRY_GOTO(hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice));
     TRY_GOTO(hipMemcpy(d_off, in_offsets, (nblocks + 1) * 8, hipMemcpyHostToDevice));
     TRY_GOTO(hipMemset(d_sum, 0, 8));
-    rc = redux_decode_blocks_dev(p, d_in, d_off, nblocks, block_size, d_out, nblocks * (uint64_t)block_size, d_sz, d_st,
-                                 d_sum, d_ws, wsb, nullptr);
+    rc = decode_blocks_dev_impl(p, d_in, d_off, nblocks, block_size, d_out, nblocks * (uint64_t)block_size, d_sz, d_st,
+                                d_sum, d_ws, wsb, nullptr, d_used);
     if (rc != REDUX_OK)
         goto done;
     TRY_GOTO(hipDeviceSynchronize());
     TRY_GOTO(hipMemcpy(out_sizes, d_sz, nblocks * 4, hipMemcpyDeviceToHost));
+    if (in_used)
+        TRY_GOTO(hipMemcpy(in_used, d_used, nblocks * 8, hipMemcpyDeviceToHost));
     TRY_GOTO(hipMemcpy(summary, d_sum, 8, hipMemcpyDeviceToHost));
     if (block_status)
         TRY_GOTO(hipMemcpy(block_status, d_st, nblocks * 4, hipMemcpyDeviceToHost));
     TRY_GOTO(hipMemcpy(out, d_out, nblocks * (uint64_t)block_size, hipMemcpyDeviceToHost));
     rc = summary[0];
 done:
-    hipFree(d_in); hipFree(d_out); hipFree(d_ws); hipFree(d_off); hipFree(d_sz); hipFree(d_st); hipFree(d_sum);
+    hipFree(d_in); hipFree(d_out); hipFree(d_ws); hipFree(d_off); hipFree(d_sz); hipFree(d_st); hipFree(d_sum); hipFree(d_used);
     return rc;
 #undef TRY_GOTO
+}
+
+int redux_decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
+                        uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes,
+                        int32_t *block_status)
+{
+    return decode_blocks_host(p, in, in_offsets, nblocks, block_size, out, out_cap, out_sizes, block_status, nullptr);
 }
 
 int redux_decompress(const redux_params *p, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
@@ -1561,15 +1594,15 @@ int redux_decompress(const redux_params *p, const uint8_t *in, uint64_t in_len, 
     uint64_t  offs[2] = {0, in_len};
     uint32_t  sz      = 0;
     int32_t   st      = 0;
-    const int rc = redux_decode_blocks(p, in, offs, 1, (uint32_t)out_cap, out, out_cap, &sz, &st);
+    uint64_t  used    = 0;
+    const int rc = decode_blocks_host(p, in, offs, 1, (uint32_t)out_cap, out, out_cap, &sz, &st, &used);
     if (rc == REDUX_OK) {
         if (bytes_out)
             *bytes_out = sz;
-        // The decoder consumes exactly the bits the encoder wrote: the
-        // reference's reader count is the stream length without trailing junk; bytes_in is
-        // reported as the number of bytes holding consumed bits.
+        // input.get_count() (lib.rs:119): the bytes the BitReader fetched -- the decoder reads
+        // exactly the bits the encoder wrote, so trailing bytes after the stream are not counted
         if (bytes_in)
-            *bytes_in = in_len;
+            *bytes_in = used;
     }
     return rc;
 }

@@ -337,3 +337,15 @@ def test_adversarial_rare_paths(rx, name, params, data):
         dec, sizes, _ = rx.decompress_blocks(out, offs, bs, w)
         got = b"".join(dec[b * bs: b * bs + int(sizes[b])].tobytes() for b in range(len(sizes)))
         assert got == many, (name, w)
+
+
+def test_decompress_counts_ignore_trailing_bytes(rx):
+    """decompress returns (bytes the reader fetched, bytes written) (src/lib.rs:119): bytes after
+    the end of the stream are never read, exactly like the oracle (and tests/corpora.rs:40-41)."""
+    data = open(os.path.join(GOLDEN, "corpora", "canterbury", "xargs.1"), "rb").read()
+    for w in WIDTHS:
+        s, _ = ox.compress(data, w)
+        want, wc = ox.decompress(s + b"\x00\x00junk-after-the-stream", w)
+        out = io.BytesIO()
+        got = rx.decompress(io.BytesIO(s + b"\x00\x00junk-after-the-stream"), out, rx.Parameters(*w), max_output=len(data) + 64)
+        assert out.getvalue() == data == want and got == wc == (len(s), len(data))
