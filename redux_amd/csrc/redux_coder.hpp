@@ -359,7 +359,11 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
     S.pend            = P - Pz + j;
     const uint32_t m  = k + Pz;
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(m > 32) == 0, 1)) {
-        S.acc = (S.acc << m) | (topk + (((1u << Pz) - 1u) << ((k - 1u) & 31u)));
+        // "b, then Pz copies of !b" is (2^Pz - 1) + b in Pz+1 bits: v_bfm_b32 builds
+        // ((1 << Pz) - 1) << (k - 1) in one instruction (both fields are taken mod 32)
+        uint32_t run;
+        asm("v_bfm_b32 %0, %1, %2" : "=v"(run) : "v"(Pz), "v"(k - 1u));
+        S.acc = (S.acc << m) | (topk + run);
         const uint32_t nb = S.nb + m;
         if (nb >= 32)
             emit_dword<false>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u))), wbase, 0);
