@@ -349,3 +349,42 @@ def test_decompress_counts_ignore_trailing_bytes(rx):
         out = io.BytesIO()
         got = rx.decompress(io.BytesIO(s + b"\x00\x00junk-after-the-stream"), out, rx.Parameters(*w), max_output=len(data) + 64)
         assert out.getvalue() == data == want and got == wc == (len(s), len(data))
+
+
+def test_container_and_cli_end_to_end(rx, tmp_path):
+    """the block container round-trips, every payload equals the oracle's
+    per-block stream, and the CLI keeps the reference's behaviour (src/main.rs): raw mode is
+    byte-identical to redux::compress, the stderr summary and exit codes match."""
+    import subprocess
+    import sys
+    from redux_amd import container
+    src = os.path.join(GOLDEN, "corpora", "canterbury", "alice29.txt")
+    data = open(src, "rb").read()
+    blob = container.compress_bytes(data, BLOCK, (8, 30, 32))
+    P, bs, total, offs, payload = container.unpack(blob)
+    want, _ = ox.compress_blocks(data, BLOCK, (8, 30, 32))
+    assert split(payload, offs) == want and total == len(data) and bs == BLOCK
+    assert container.decompress_bytes(blob) == data
+    assert container.decompress_bytes(container.compress_bytes(b"", BLOCK)) == b""
+
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    run = lambda *a: subprocess.run([sys.executable, "-m", "redux_amd.cli", *a], capture_output=True, env=env, timeout=120)
+    raw, blk, back1, back2 = (str(tmp_path / n) for n in ("raw.rdx", "blk.rdx", "b1", "b2"))
+    r = run("-c", "-i", src, "-o", raw)                       # reference-compatible single stream
+    whole, _ = ox.compress(data, (8, 30, 32))
+    assert r.returncode == 0 and open(raw, "rb").read() == whole
+    assert r.stderr.decode().strip() == "Compressed %d bytes into %d bytes, ratio: %.3f" % (len(data), len(whole), len(data) / len(whole))
+    r = run("-d", "-i", raw, "-o", back1)
+    assert r.returncode == 0 and open(back1, "rb").read() == data
+    assert r.stderr.decode().strip() == "Decompressed %d bytes from %d bytes, ratio: %.3f" % (len(data), len(whole), len(data) / len(whole))
+    r = run("-c", "-i", src, "-o", blk, "--block-size", "65536")
+    assert r.returncode == 0 and open(blk, "rb").read() == blob
+    r = run("-d", "-i", blk, "-o", back2)
+    assert r.returncode == 0 and open(back2, "rb").read() == data
+    r = run("-d", "-i", src, "-o", back2)                       # not a stream: Eof or garbage-but-no-crash
+    assert r.returncode in (0, 3)
+    open(raw, "wb").write(whole[: len(whole) // 2])
+    r = run("-d", "-i", raw, "-o", back1)
+    assert r.returncode == 3 and r.stderr.decode().strip() == "Decompression error: Unexpected end of file"
+    r = subprocess.run([sys.executable, "-m", "redux_amd.cli", "-c"], input=b"redux", capture_output=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout == ox.compress(b"redux", (8, 30, 32))[0]   # stdin -> stdout
