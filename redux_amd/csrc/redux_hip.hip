@@ -222,8 +222,12 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
 // Eight waves per CU = two per SIMD, so each SIMD always has a second instruction stream to
 // issue from.  (Measured, profiles/r01_ubench: a gfx950 SIMD retires the VOP3-type ops this
 // code is made of at ~4.5 cycles per wave-instruction however many waves feed it, so the two
-// streams together run at the SIMD's VALU rate; a third wave -- the model split by tree
-// level -- was built and measured 35 % SLOWER, and was removed.)  The ring holds 2 x 8 symbols x 64 lanes x 8 B = 8 KiB (40 KiB per workgroup,
+// streams together run at the SIMD's VALU rate.  Two three-wave variants were built, passed
+// the whole parity suite and were removed because they were slower: the model split by tree
+// level (+35 %: duplicated per-symbol work) and a three-stage pipeline nodes -> sums -> coder
+// with no duplicated work (+83 %: the LDS only has room for 2-symbol ring halves, and three
+// synchronised waves get LESS aggregate VALU throughput than two, 5.7 vs 4.9 cycles per
+// instruction in tools/ubench "40 VALU + barrier").)  The ring holds 2 x 8 symbols x 64 lanes x 8 B = 8 KiB (40 KiB per workgroup,
 // four workgroups = the CU's 160 KiB exactly); one s_barrier per 8 symbols hands a half over.
 // Only LDS traffic must be complete at the hand-off, so the barrier waits on lgkmcnt alone:
 // the coder's stores and the model's prefetch loads stay in flight across it.

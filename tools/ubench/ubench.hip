@@ -254,6 +254,25 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed, unsigned 
 #pragma unroll
             for (int b = 0; b < 8; b++) { uint32_t t; asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"(a[b])); asm volatile("" :: "v"(t)); }
             asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (T == 70) { // bare barrier
+#pragma unroll
+            for (int b = 0; b < 8; b++) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else if (T == 71) { // barrier + LDS hand-off: write my slot, barrier, read the other wave's slot
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                my[((wave * 64 + lane) & 255) + 256 * (b & 1)] = x[b];
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                x[b] += my[(((wave + 1) * 64 + lane) & 255) + 256 * (b & 1)];
+            }
+        } else if (T == 72) { // 40 independent VALU between barriers (a "2-symbol phase" of work)
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+#pragma unroll
+                for (int r = 0; r < 5; r++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x[c]) : "s"(seed), "v"(a[c]));
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
         } else if (T == 20) { // SALU
 #pragma unroll
             for (int b = 0; b < 16; b++) asm volatile("s_add_u32 %0, %0, 3" : "+s"(seed));
@@ -302,7 +321,7 @@ int main()
     double ghz = (double)hc[0] / (double)hc[1] * 0.1;
     printf("measured shader clock (idle chip): %.3f GHz; hipDeviceProp clockRate %.2f GHz\n", ghz, p.clockRate / 1e6);
     printf("device %s clock %.2f GHz CUs %d\n", p.name, ghz, p.multiProcessorCount);
-    for (int cfg = 0; cfg < 2; cfg++) {
+    for (int cfg = 0; cfg < 4; cfg++) {
         int th = cfg == 0 ? 64 : cfg == 1 ? 128 : cfg == 2 ? 192 : 256; size_t l = 40960; // 4 workgroups per CU by LDS
         printf("---- %d wave(s) per workgroup x 4 workgroups per CU = %d waves/SIMD\n", th / 64, th / 64);
         run<0>("empty loop", 1, th, l, ghz);
@@ -359,6 +378,9 @@ int main()
         run<67>("8x ds_read_b64 (latency each)", 8, th, l, ghz);
         run<68>("8x ds_write_b64 throughput", 8, th, l, ghz);
         run<69>("8x ds_read_b32 throughput", 8, th, l, ghz);
+        run<70>("8x s_barrier", 8, th, l, ghz);
+        run<71>("8x (lds write, barrier, lds read)", 8, th, l, ghz);
+        run<72>("8x (40 VALU + barrier)", 8, th, l, ghz);
         run<20>("16x s_add_u32 dependent", 16, th, l, ghz);
     }
     return 0;
