@@ -306,24 +306,30 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
                                             uint32_t p, uint32_t nfreeze)
 {
     const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+    auto sym = [&](int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; };
     // software pipeline: symbol i+1's LDS ops are in flight while symbol i's sums are formed
-    Tree<true>::Nodes nc = T.template issue<UPD>(w[0] & 0xFFu, true);
+    // (depths 2 and 3 measured no faster: the wave is bound by its own issue rate, not by LDS)
+    constexpr int D = 1;
+    Tree<true>::Nodes q[D + 1];
+#pragma unroll
+    for (int d = 0; d < D; d++)
+        q[d] = T.template issue<UPD>(sym(d), true);
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const uint32_t s   = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const uint32_t s   = sym(i);
         const uint32_t nup = UPD ? p + i : nfreeze;
-        Tree<true>::Nodes nn;
-        if (i + 1 < 16) {
-            nn = T.template issue<UPD>((w[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu, true);
+        if (i + D < 16) {
+            q[D] = T.template issue<UPD>(sym(i + D), true);
             __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t lo, hi;
-        T.finish(s, nup, nc, lo, hi);
+        T.finish(s, nup, q[0], lo, hi);
         ring[i * 64 + lane] = make_uint2(lo, hi);
         if ((i & 7) == 7)
             pair_barrier();
-        if (i + 1 < 16)
-            nc = nn;
+#pragma unroll
+        for (int d = 0; d < D; d++)
+            q[d] = q[d + 1];
     }
 }
 
@@ -371,6 +377,8 @@ template <bool FIXUP>
 __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
 {
     __shared__ uint32_t lds[Tree<true>::kDwords + kRingBytes / 4];
+    // wave 0 = model, wave 1 = coder.  A census with this launch shape (tools/ubench/census.hip)
+    // shows every SIMD holding exactly one wave 0 and one wave 1 of different workgroups.
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t blk0 = (uint64_t)blockIdx.x * a.lanes;
