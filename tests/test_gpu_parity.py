@@ -389,3 +389,36 @@ def test_container_and_cli_end_to_end(rx, tmp_path):
     assert r.returncode == 3 and last(r) == "Decompression error: Unexpected end of file"
     r = subprocess.run([sys.executable, "-m", "redux_amd.cli", "-c"], input=b"redux", capture_output=True, env=env, timeout=120)
     assert r.returncode == 0 and r.stdout == ox.compress(b"redux", (8, 30, 32))[0]   # stdin -> stdout
+
+
+@pytest.mark.parametrize("kind", ["iid", "zipf"])
+def test_full_size_config_roundtrip(rx, kind):
+    """BASELINE.json configs[1] / configs[4] shape at FULL size on one GPU (65,536 blocks of
+    64 KiB = 4 GiB): size-independent properties -- no block reports an error, decode(encode(x))
+    == x compared on device, offsets are monotone and consistent with the sizes -- plus blocks
+    sampled across the whole range compared byte for byte with the oracle."""
+    import torch
+    nblocks = 65536
+    n = nblocks * BLOCK
+    d_in = rx.gen_iid(n) if kind == "iid" else rx.gen_zipf(n)
+    enc = rx.DeviceEncoder((8, 30, 32), BLOCK, n)
+    out, offs, status, summary = enc.encode(d_in)
+    torch.cuda.synchronize()
+    assert summary.tolist() == [0, 0]
+    sizes = offs[1:] - offs[:-1]
+    assert int(offs[0]) == 0 and bool((sizes > 0).all()) and int(sizes.max()) <= 74752
+    total = int(offs[-1])
+    ratio = total / n
+    assert (1.0 < ratio < 1.01) if kind == "iid" else (0.6 < ratio < 0.72), ratio
+    offs_h = offs.cpu().numpy()
+    for b in [0, 1, 63, 64, 4095, 4096, 32767, 32768, 65471, 65535]:
+        blk = d_in[b * BLOCK:(b + 1) * BLOCK].cpu().numpy().tobytes()
+        want, _ = ox.compress(blk, (8, 30, 32))
+        assert out[int(offs_h[b]): int(offs_h[b + 1])].cpu().numpy().tobytes() == want, b
+    dec = rx.DeviceDecoder((8, 30, 32), BLOCK, nblocks)
+    d_out, d_sizes, d_status, d_sum = dec.decode(out[:total], offs)
+    torch.cuda.synchronize()
+    assert d_sum.tolist() == [0, 0] and bool((d_sizes == BLOCK).all())
+    assert torch.equal(d_out, d_in)
+    del dec, enc, d_in, d_out, out
+    torch.cuda.empty_cache()
