@@ -163,6 +163,21 @@ struct Tree {
             hi = hs + (m >> 8) * d256;
         }
     }
+    // cum(s+1) alone (the decoder knows cum(s) from its descent): half of finish()
+    __device__ __forceinline__ uint32_t finish_high(uint32_t s, uint32_t d256, const Nodes &n) const
+    {
+        static_assert(U16, "u16 tree only");
+        const uint32_t m  = s + 1;
+        const uint32_t um = m * 0x8001u;
+        uint32_t       hs = (m >> 8) * d256 + m;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(n.x[2 * j + 1], n.x[2 * j], sel));
+            hs = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, (um >> (2 * j)) & 0x10001u), hs, false);
+        }
+        return hs;
+    }
+
     template <bool UPD>
     __device__ __forceinline__ void get_frequency(uint32_t s, uint32_t d256, bool upd, uint32_t &lo,
                                                   uint32_t &hi) const

@@ -734,6 +734,7 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
 //   * the bit buffer keeps the upcoming bits left-aligned, so "take n bits" is just its high
 //     dword: the window update is two 64-bit shifts on [value | next 32 bits].
 // --------------------------------------------------------------------------------------
+template <bool CB32>
 __global__ void __launch_bounds__(64) k_decode_fast(DecArgs a)
 {
     __shared__ uint32_t lds[Tree<true>::kDwords];
@@ -747,7 +748,7 @@ __global__ void __launch_bounds__(64) k_decode_fast(DecArgs a)
     Tree<true> T;
     T.init(lds, lane);
 
-    const uint32_t cb = a.code_bits, sh = 32 - cb;
+    const uint32_t cb = CB32 ? 32u : a.code_bits, sh = CB32 ? 0u : 32 - cb; // code_bits == 32: no alignment shifts
     uint64_t       size = 0;
     const uint8_t *sp   = a.in;
     if (live) {
@@ -892,8 +893,8 @@ __global__ void __launch_bounds__(64) k_decode_fast(DecArgs a)
                 rem -= b0 ? t : 0u;
                 s                 = i | (b1 ? 2u : 0u) | (b0 ? 1u : 0u);
             }
-            uint32_t lo, hi;
-            T.finish(s, nup, nodes, lo, hi); // lo == v - rem as well
+            const uint32_t lo = v - rem; // cum(s): what the descent subtracted
+            const uint32_t hi = T.finish_high(s, nup, nodes);
             if (p < nfreeze && !is_eof) { // update(s+1), adaptive_tree.rs:83-92
                 const uint32_t ss  = s << 7;
                 const uint32_t nsl = (s ^ 0xFFu) << hsh;
@@ -1505,8 +1506,10 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     a.in_used    = (uint64_t *)d_in_used;
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
     const char *force = getenv("REDUX_DECODE_KERNEL"); // "generic" pins k_decode (A/B timing only)
-    if (g.u16 && !g.fixup && !(force && !strcmp(force, "generic")))
-        k_decode_fast<<<grid, 64, 0, s>>>(a);
+    if (g.u16 && !g.fixup && !(force && !strcmp(force, "generic")) && p->code_bits == 32)
+        k_decode_fast<true><<<grid, 64, 0, s>>>(a);
+    else if (g.u16 && !g.fixup && !(force && !strcmp(force, "generic")))
+        k_decode_fast<false><<<grid, 64, 0, s>>>(a);
     else if (g.u16 && !g.fixup)
         k_decode<true, false><<<grid, 64, 0, s>>>(a);
     else if (g.u16)
