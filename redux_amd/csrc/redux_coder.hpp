@@ -139,6 +139,7 @@ struct Tree {
     {
         const uint32_t m = s + 1;
         if (U16) {
+            const uint32_t *xs = n.x;
             const uint32_t us = s * 0x8001u;
             const uint32_t um = us + 0x8001u;
             uint32_t       ls = s;
@@ -146,7 +147,7 @@ struct Tree {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // [lo16 = this lane's d[e_2j], hi16 = this lane's d[e_2j+1]]
-                const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(n.x[2 * j + 1], n.x[2 * j], sel));
+                const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(xs[2 * j + 1], xs[2 * j], sel));
                 ls = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, (us >> (2 * j)) & 0x10001u), ls, false);
                 hs = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, (um >> (2 * j)) & 0x10001u), hs, false);
             }

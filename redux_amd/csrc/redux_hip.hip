@@ -235,10 +235,34 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
 constexpr uint32_t kRingSlots = 8;                               // symbols per hand-off
 constexpr uint32_t kRingBytes = 2 * kRingSlots * 64 * 8;         // two halves of uint2[8][64]
 
+#ifdef REDUX_STAMPS
+// Diagnostic build only (never timed, never shipped): every ring barrier is bracketed by
+// s_memtime; lane 0 of each wave accumulates {last stamp, cycles between barriers, cycles
+// inside barriers, count} in the tree's unused row 0 (LDS bytes 0..63) and the kernel copies
+// them to the spare slot at exit.  The barrier drains lgkmcnt anyway, so the stamps do not
+// change what the waves overlap.
+typedef __attribute__((address_space(3))) unsigned long long *lds64p;
+__device__ __forceinline__ void pair_barrier()
+{
+    unsigned long long t0, t1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1)::"memory");
+    if ((threadIdx.x & 63) == 0) {
+        lds64p a = (lds64p)(uintptr_t)((threadIdx.x >> 6) * 32);
+        const unsigned long long prev = a[0];
+        if (prev)
+            a[1] += t0 - prev;
+        a[2] += t1 - t0;
+        a[0] = t1;
+        a[3] += 1;
+    }
+}
+#else
 __device__ __forceinline__ void pair_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+#endif
 
 // Input path of the model wave: every lane reads its own block one whole 128-byte line at a
 // time (eight 16-byte loads issued back to back), so each line crosses the L2 <-> fabric
@@ -469,6 +493,13 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
         }
     }
     __syncthreads(); // the model wave's last updates are in LDS before the tail reads the tree
+#ifdef REDUX_STAMPS
+    if (lane == 0) {
+        lds64p st = (lds64p)(uintptr_t)(wave * 32);
+        unsigned long long *dstp = reinterpret_cast<unsigned long long *>(a.slots + a.nblocks * a.slot_bytes) + (blockIdx.x * 2 + wave) * 4;
+        dstp[0] = st[1]; dstp[1] = st[2]; dstp[2] = st[3]; dstp[3] = wave;
+    }
+#endif
     if (wave == 0)
         return;
 
