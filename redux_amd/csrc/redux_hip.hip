@@ -1308,11 +1308,22 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
         rpo += need ? 1u : 0u;                                                                                         \
         fetched = ring_read(rpo);                                                                                      \
     }
-    // once per group of four steps: retire the chunk requested a group ago, request the next
-#define REDUX_DEC_PRODUCER                                                                                             \
+    // Once per group of four steps, in this order (vmcnt counts loads AND stores, in order, so
+    // the one wait of a group must find nothing younger than a group in flight):
+    //   RETIRE  wait for the chunk requested a group ago and move it into the ring;
+    //   STORE   the four symbols the previous group produced;
+    //   REQUEST the next chunk.
+#define REDUX_DEC_RETIRE                                                                                               \
+    if (pend)                                                                                                          \
+        ring_write(pend_chunk, ldq.x, ldq.y, ldq.z, ldq.w);
+#define REDUX_DEC_STORE                                                                                                \
+    if (aligned4 && S.n_out == p && p > stored) {                                                                      \
+        *reinterpret_cast<uint32_t *>(dst + (p - 4)) = S.obuf;                                                         \
+        S.obuf = 0;                                                                                                    \
+        stored = p;                                                                                                    \
+    }
+#define REDUX_DEC_REQUEST                                                                                              \
     {                                                                                                                  \
-        if (pend)                                                                                                      \
-            ring_write(pend_chunk, ldq.x, ldq.y, ldq.z, ldq.w);                                                        \
         const bool room = (int32_t)(4u * wr - rpo) <= 28;                                                              \
         const bool tail = 4u * wr + 3u > rpo_last;                                                                     \
         pend       = room;                                                                                             \
@@ -1344,7 +1355,9 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
         for (; p + 4 <= pfast; p += 4) {
             if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
                 break;
-            REDUX_DEC_PRODUCER
+            REDUX_DEC_RETIRE
+            REDUX_DEC_STORE
+            REDUX_DEC_REQUEST
 #pragma unroll
             for (int K = 0; K < 4; K++) {
                 const double   rc = rcp[p + K];
@@ -1426,11 +1439,6 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
                 cd += 1.0;
                 DEC_STAMP(6, S.low + S.W)
             }
-            if (S.n_out == p + 4) {
-                *reinterpret_cast<uint32_t *>(dst + p) = S.obuf;
-                S.obuf = 0;
-                stored = p + 4;
-            }
         }
     }
 #ifdef REDUX_DEC_STAMPS
@@ -1445,14 +1453,12 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
         const uint32_t nup = p < nfreeze ? p : nfreeze;
         const double   rc  = rcp[nup];
         const uint32_t c   = 257u + nup;
-        if ((p & 3) == 0)
-            REDUX_DEC_PRODUCER
-        REDUX_DEC_READER
-        if ((p & 3) == 0 && aligned4 && S.n_out == p && p > stored) {
-            *reinterpret_cast<uint32_t *>(dst + (p - 4)) = S.obuf;
-            S.obuf = 0;
-            stored = p;
+        if ((p & 3) == 0) {
+            REDUX_DEC_RETIRE
+            REDUX_DEC_STORE
+            REDUX_DEC_REQUEST
         }
+        REDUX_DEC_READER
         const uint32_t R1  = (~(S.ihigh + S.low)) >> sh;
         const uint32_t Vd  = (S.W - S.low) >> sh;
         const double   R1d = (double)R1;
@@ -1461,7 +1467,9 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
         dec_commit_careful<CB32>(S, T, f, lds, A, R1, R1d, rc, c, sh, stream_bits, p, p < nfreeze, p < capn, aligned4, dst);
     }
 #undef REDUX_DEC_READER
-#undef REDUX_DEC_PRODUCER
+#undef REDUX_DEC_RETIRE
+#undef REDUX_DEC_STORE
+#undef REDUX_DEC_REQUEST
     if (live) {
         if (aligned4)
             for (uint32_t i = stored; i < S.n_out; i++)
