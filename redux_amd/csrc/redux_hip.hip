@@ -1352,15 +1352,24 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
 #endif
     if (aligned4) {
         double cdm1 = 256.0, cd = 257.0;
+        // the group's four reciprocals are loaded a group ahead: one scalar load per group, and
+        // its latency never sits in front of an LDS wait (SMEM and LDS share lgkmcnt)
+        double rcg[4], rcn[4];
+#pragma unroll
+        for (int K = 0; K < 4; K++)
+            rcg[K] = rcp[K];
         for (; p + 4 <= pfast; p += 4) {
             if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
                 break;
+#pragma unroll
+            for (int K = 0; K < 4; K++)
+                rcn[K] = rcp[p + 4 + K]; // the table has 8 entries of slack (geometry())
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
             REDUX_DEC_REQUEST
 #pragma unroll
             for (int K = 0; K < 4; K++) {
-                const double   rc = rcp[p + K];
+                const double   rc = rcg[K];
                 const uint32_t c  = 257u + p + K;
                 REDUX_DEC_READER
                 DEC_STAMP(0, S.bcnt)
@@ -1439,6 +1448,9 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
                 cd += 1.0;
                 DEC_STAMP(6, S.low + S.W)
             }
+#pragma unroll
+            for (int K = 0; K < 4; K++)
+                rcg[K] = rcn[K];
         }
     }
 #ifdef REDUX_DEC_STAMPS
@@ -1758,6 +1770,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.rc_n  = (uint32_t)((maxlen < g.nfreeze ? maxlen : g.nfreeze) + 1);
     g.u16   = block_size <= 65536;
     g.fixup = (257ull + (uint64_t)(g.rc_n - 1)) >= (1ull << 17);
+    g.rc_n += 8; // slack: the decoder loads its reciprocals eight at a time, a group ahead, without clamping
     g.off_rc    = 0;
     g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
     g.off_slots = align_up(g.off_sizes + g.nblocks * 4, 256);
