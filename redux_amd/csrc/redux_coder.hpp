@@ -336,31 +336,28 @@ __device__ __forceinline__ uint32_t encode_symbol(EncState &S, uint32_t lo, uint
     return k + j;
 }
 
-// Hot-loop version of encode_symbol for data symbols (never EOF), all 64 lanes active.
-// Differences from encode_symbol, none of them visible in the stream:
-//   * the dword store is UNCONDITIONAL and speculative: every symbol stores the accumulator's
-//     current top 32 bits at `off`; `off` only advances once a group is complete, so the last
-//     store at any offset is always the completed group (earlier ones are overwritten in
-//     L2).  This removes the compare + exec-mask save/restore around a predicated store.
-//     The caller guarantees off + 4 <= limit for the whole chunk.
-//   * the long-pending-run case is detected with one wave-level ballot.
-template <bool FIXUP>
+// Hot-loop version of encode_symbol for data symbols (never EOF), all 64 lanes active; the
+// caller guarantees off + 4 <= limit for the whole chunk.  Differences from encode_symbol,
+// none of them visible in the stream:
+//   * the long-pending-run case is detected with one wave-level ballot;
+//   * only the store of a completed group is predicated: `off` advances by arithmetic;
+//   * CB32 (code_bits == 32) drops the alignment shifts.
+template <bool FIXUP, bool CB32 = false>
 __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uint32_t hi, uint32_t c, double rc,
-                                                   uint32_t sh, uint8_t *wbase)
+                                                   uint32_t sh_, uint8_t *wbase)
 {
+    const uint32_t sh = CB32 ? 0u : sh_; // code_bits == 32: the alignment shifts vanish
     const uint32_t R1 = (~(S.ihigh + S.low)) >> sh;
     const double   Y  = __builtin_fma((double)R1, rc, rc);
     const uint32_t nlow   = S.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
-    const uint32_t nihigh = 0u - (S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh)); // ~(new high) = -(high + 1)
+    uint32_t       nihigh = 0u - (S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh)); // ~(new high) = -(high + 1)
+    asm volatile("" : "+v"(nihigh)); // opaque: low ^ high is then one v_xnor, not (high+1)-1 followed by v_xor
 
-    // k = clz(low ^ high) through v_ffbh_u32, which returns -1 for low == high (k = 32).
-    // Masked to 6 bits that is 63: the 64-bit shifts then shift everything out exactly as
-    // k = 32 would, so the state update needs no clamp (v_min is a half-rate op here); the
-    // emission sees k + P > 32 and takes the careful path, which uses the clamped k.
+    // k = clz(low ^ high), 32 for low == high (v_ffbh + v_min).  The 64-bit shifts then shift
+    // everything out, so the state update needs no special case; the emission takes the careful
+    // path whenever k + P > 32 (for k == 32 and P == 0 the common path appends all 32 bits).
     const uint32_t x    = ~(nlow ^ nihigh);
-    uint32_t       kraw;
-    asm("v_ffbh_u32 %0, %1" : "=v"(kraw) : "v"(x));
-    const uint32_t k    = kraw & 63u; // 0..31, or 63 for low == high
+    const uint32_t k    = x ? (uint32_t)__builtin_clz(x) : 32u;
     const uint64_t sl   = (uint64_t)nlow << k;
     const uint32_t topk = (uint32_t)(sl >> 32);
     const uint32_t low2 = (uint32_t)sl;
@@ -381,12 +378,18 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
         asm("v_bfm_b32 %0, %1, %2" : "=v"(run) : "v"(Pz), "v"(k - 1u));
         S.acc = (S.acc << m) | (topk + run);
         const uint32_t nb = S.nb + m;
+#ifndef REDUX_STORE_X4
+        if (nb >= 32) // the only predicated instruction group: shift, byte swap, store
+            *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u)));
+        S.off += (nb >> 3) & 4u; // nb < 64: +4 exactly when a group completed
+#else
         if (nb >= 32)
             emit_dword<false>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u))), wbase, 0);
+#endif
         S.nb = nb & 31u;
-    } else { // some lane has a pending run too long for one append (or k = 32): careful path for all
-        const uint32_t kk = k > 32 ? 32u : k;
-        const uint32_t tk = k > 32 ? nlow : topk;
+    } else { // some lane has a pending run too long for one append: careful path for all
+        const uint32_t kk = k;
+        const uint32_t tk = topk;
         if (kk + Pz <= 32) {
             put_bits(S, tk + (((1u << Pz) - 1u) << ((kk - 1u) & 31u)), kk + Pz, wbase, 0xFFFFFFFFu);
         } else {

@@ -357,15 +357,17 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
     }
 }
 
-// MODE 0: adaptive chunk (reciprocals rc[p..p+15]); MODE 1: frozen chunk (rc[nfreeze])
-template <bool FIXUP, int MODE>
+// MODE 0: adaptive chunk (reciprocals rc[p..p+15]); MODE 1: frozen chunk (rc[nfreeze]).
+// MODE 0 takes the reciprocals of its first eight symbols in r[] and leaves those of the next
+// chunk's first eight there: each half loads the following half's eight right after its own
+// ring reads have arrived, at the start of an eight-symbol stretch with no lgkmcnt wait in it.
+// (SMEM shares lgkmcnt with LDS and returns out of order, so any LDS wait or ring barrier also
+// waits for every scalar load in flight; loaded at the top of the chunk, their miss latency sat
+// in front of the first barrier.  Sixteen at a time would need 64 SGPRs: spills.)
+template <bool FIXUP, int MODE, bool CB32>
 __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint32_t lane, uint32_t p,
-                                            uint32_t nfreeze, rc_ptr rc, uint32_t sh, uint8_t *wdst)
+                                            uint32_t nfreeze, rc_ptr rc, uint32_t sh, uint8_t *wdst, double (&r)[8])
 {
-    double r[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++)
-        r[i] = rc[MODE == 0 ? p + i : nfreeze];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         pair_barrier();
@@ -373,10 +375,26 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
 #pragma unroll
         for (int i = 0; i < 8; i++)
             lh[i] = ring[(h * 8 + i) * 64 + lane];
+        double rn[8];
+        if (MODE == 0) {
+            uint32_t zero; // opaque 0 that "depends" on the ring data: pins the loads behind the LDS wait
+            asm volatile("s_mov_b32 %0, 0" : "=s"(zero) : "v"(lh[0].x));
+            const rc_ptr nb = rc + (p + 8u * h + 8u + zero); // the table has 32 entries of slack (geometry())
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                rn[i] = nb[i];
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
-            encode_symbol_fast<FIXUP>(S, lh[i].x, lh[i].y, 257u + nup, r[h * 8 + i], sh, wdst);
+            uint32_t       hi  = lh[i].y;
+            asm volatile("" : "+v"(hi)); // keeps ISel from turning (u64 >> 32) -> f64 into a 64-bit conversion (+1 v_add_f64)
+            encode_symbol_fast<FIXUP, CB32>(S, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                r[i] = rn[i];
         }
     }
 }
@@ -397,7 +415,7 @@ __device__ __forceinline__ void coder_chunk_checked(EncState &S, const uint2 *ri
     }
 }
 
-template <bool FIXUP>
+template <bool FIXUP, bool CB32>
 __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
 {
     __shared__ uint32_t lds[Tree<true>::kDwords + kRingBytes / 4];
@@ -483,13 +501,21 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
     } else {
         // ---------------- coder wave ----------------
         uint32_t p = 0;
+        double   r[8];      // reciprocals of the first eight symbols of chunk r_at
+        uint32_t r_at = ~0u;
         for (; p < main_end; p += 16) {
             if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit) || (p >= a_end && p < m_end))
                 coder_chunk_checked<FIXUP>(S, ring, lane, p, nfreeze, rc, sh, wdst, limit);
-            else if (p < a_end)
-                coder_chunk<FIXUP, 0>(S, ring, lane, p, nfreeze, rc, sh, wdst);
-            else
-                coder_chunk<FIXUP, 1>(S, ring, lane, p, nfreeze, rc, sh, wdst);
+            else if (p < a_end) {
+                if (r_at != p) { // first chunk, or the previous one took the checked path
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        r[i] = rc[p + i];
+                }
+                coder_chunk<FIXUP, 0, CB32>(S, ring, lane, p, nfreeze, rc, sh, wdst, r);
+                r_at = p + 16;
+            } else
+                coder_chunk<FIXUP, 1, CB32>(S, ring, lane, p, nfreeze, rc, sh, wdst, r);
         }
     }
     __syncthreads(); // the model wave's last updates are in LDS before the tail reads the tree
@@ -1363,7 +1389,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
                 break;
 #pragma unroll
             for (int K = 0; K < 4; K++)
-                rcn[K] = rcp[p + 4 + K]; // the table has 8 entries of slack (geometry())
+                rcn[K] = rcp[p + 4 + K]; // the table has 32 entries of slack (geometry())
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
             REDUX_DEC_REQUEST
@@ -1770,7 +1796,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.rc_n  = (uint32_t)((maxlen < g.nfreeze ? maxlen : g.nfreeze) + 1);
     g.u16   = block_size <= 65536;
     g.fixup = (257ull + (uint64_t)(g.rc_n - 1)) >= (1ull << 17);
-    g.rc_n += 8; // slack: the decoder loads its reciprocals eight at a time, a group ahead, without clamping
+    g.rc_n += 32; // slack: both coders load their reciprocals a group / a chunk ahead without clamping
     g.off_rc    = 0;
     g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
     g.off_slots = align_up(g.off_sizes + g.nblocks * 4, 256);
@@ -1873,10 +1899,11 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     // REDUX_ENCODE_KERNEL=single pins the one-wave kernel (A/B timing only)
     const char *force = getenv("REDUX_ENCODE_KERNEL");
     const bool  pair  = g.u16 && a.aligned16 && a.lanes == 64 && !(force && !strcmp(force, "single"));
-    if (pair && !g.fixup)
-        k_encode_pair<false><<<grid, 128, 0, s>>>(a);
-    else if (pair)
-        k_encode_pair<true><<<grid, 128, 0, s>>>(a);
+    // (a u16 tree means blocks of <= 65536 symbols, so count < 2^17: the pair kernel never needs FIXUP)
+    if (pair && !g.fixup && p->code_bits == 32)
+        k_encode_pair<false, true><<<grid, 128, 0, s>>>(a);
+    else if (pair && !g.fixup)
+        k_encode_pair<false, false><<<grid, 128, 0, s>>>(a);
     else if (g.u16 && !g.fixup)
         k_encode<true, false><<<grid, 64, 0, s>>>(a);
     else if (g.u16)
