@@ -143,7 +143,7 @@ struct Tree {
             const uint32_t us = s * 0x8001u;
             const uint32_t um = us + 0x8001u;
             uint32_t       ls = s;
-            uint32_t       hs = (m >> 8) * d256 + m; // bit 8 of s+1 selects the derived node 256
+            uint32_t       hs = __umul24(m >> 8, d256) + m; // bit 8 of s+1 selects the derived node 256 (d256 < 2^24: one v_mad_u32_u24)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // [lo16 = this lane's d[e_2j], hi16 = this lane's d[e_2j+1]]
@@ -164,21 +164,6 @@ struct Tree {
             hi = hs + (m >> 8) * d256;
         }
     }
-    // cum(s+1) alone (the decoder knows cum(s) from its descent): half of finish()
-    __device__ __forceinline__ uint32_t finish_high(uint32_t s, uint32_t d256, const Nodes &n) const
-    {
-        static_assert(U16, "u16 tree only");
-        const uint32_t m  = s + 1;
-        const uint32_t um = m * 0x8001u;
-        uint32_t       hs = (m >> 8) * d256 + m;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(n.x[2 * j + 1], n.x[2 * j], sel));
-            hs = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, (um >> (2 * j)) & 0x10001u), hs, false);
-        }
-        return hs;
-    }
-
     template <bool UPD>
     __device__ __forceinline__ void get_frequency(uint32_t s, uint32_t d256, bool upd, uint32_t &lo,
                                                   uint32_t &hi) const

@@ -777,245 +777,7 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
 }
 
 // --------------------------------------------------------------------------------------
-// Fast decoder: u16 tree, count < 2^17 (every block <= 64 KiB).  Same results as k_decode; the
-// differences are all about the length of the per-symbol dependent chain, which is what a
-// decoder lane is made of (the symbol search needs the code value, the next code value needs
-// the symbol's range: nothing overlaps):
-//   * value = floor(((V-low+1)*count - 1) / range) in f64: numerator and range are exact
-//     (< 2^49, <= 2^32); reciprocal = v_rcp_f64 + one Newton step, biased DOWN by 2^-40 so the
-//     truncated product is q or q-1; one exact f64 remainder (fma) adds the 1 back.
-//   * get_symbol's descent (adaptive_tree.rs:119-127) as THREE rounds of independent LDS reads
-//     (levels 7-5: 7 nodes, levels 4-2: 7 nodes, levels 1-0: 3 nodes) instead of eight
-//     dependent round trips; the raw dwords on the path feed the same finish() as the encoder
-//     (cum(s+1)), and update(s+1) is eight fire-and-forget ds_add_u32.
-//   * the bit buffer keeps the upcoming bits left-aligned, so "take n bits" is just its high
-//     dword: the window update is two 64-bit shifts on [value | next 32 bits].
-// --------------------------------------------------------------------------------------
-template <bool CB32>
-__global__ void __launch_bounds__(64) k_decode_fast(DecArgs a)
-{
-    __shared__ uint32_t lds[Tree<true>::kDwords];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
-    const bool     live = blk < a.nblocks;
-
-    for (uint32_t i = lane; i < Tree<true>::kDwords / 4; i += 64)
-        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    Tree<true> T;
-    T.init(lds, lane);
-
-    const uint32_t cb = CB32 ? 32u : a.code_bits, sh = CB32 ? 0u : 32 - cb; // code_bits == 32: no alignment shifts
-    uint64_t       size = 0;
-    const uint8_t *sp   = a.in;
-    if (live) {
-        const uint64_t o0 = a.in_offsets[blk];
-        size              = a.in_offsets[blk + 1] - o0;
-        sp                = a.in + o0;
-    }
-    const uint32_t stream_bits = (uint32_t)(size * 8); // size <= slot of a 64 KiB block
-    uint8_t       *dst         = a.out + (live ? blk : 0) * (uint64_t)a.block_size;
-    const uint32_t capn        = a.block_size;
-    const rc_ptr   rcp         = (rc_ptr)a.rc;
-    const uint32_t nfreeze     = a.nfreeze;
-
-    // Bit reader state (bitio/mod.rs:78-120) as dword offsets from the 4-byte-aligned start of
-    // the input buffer (global address space, so the loads are global_load, not flat):
-    //   bbits/bcnt  upcoming bits, left-aligned, and how many are valid
-    //   nextw       the following dword, already in a register
-    //   fetched     the dword after that, in flight since the previous step
-    typedef const __attribute__((address_space(1))) uint32_t *gptr;
-    const uintptr_t in_base = (uintptr_t)a.in & ~(uintptr_t)3;
-    const gptr      gin     = (gptr)in_base;
-    const uintptr_t sp_abs  = (uintptr_t)sp;
-    uint32_t        rpo     = (uint32_t)(((sp_abs & ~(uintptr_t)3) - in_base) >> 2);
-    const uint32_t  rpo_end = live ? (uint32_t)((((sp_abs + size + 3) & ~(uintptr_t)3) - in_base) >> 2) : rpo;
-    const uint32_t  skip    = (uint32_t)(sp_abs & 3) * 8;
-    auto rd = [&](uint32_t o) { return (live && o < rpo_end) ? gin[o] : 0u; };
-    uint64_t bbits = ((uint64_t)__builtin_bswap32(rd(rpo)) << 32 | __builtin_bswap32(rd(rpo + 1))) << skip;
-    uint32_t bcnt  = 64 - skip;
-    uint32_t nextw = rd(rpo + 2), fetched = nextw; // nothing in flight yet
-    rpo += 3;
-    // decompress_symbol's first call pulls code_bits bits (codec.rs:124-127)
-    uint32_t W = (uint32_t)((bbits >> 1) >> (63 - cb)) << sh;
-    bbits <<= cb;
-    bcnt -= cb;
-    uint32_t consumed = cb;
-    uint32_t low = 0, high = 0xFFFFFFFFu;
-    int32_t  st   = REDUX_OK;
-    bool     done = !live;
-    if (live && consumed > stream_bits) {
-        st   = REDUX_EOF;
-        done = true;
-    }
-    uint32_t n_out = 0, stored = 0;
-    uint32_t obuf  = 0;
-    const uint32_t L = T.L, hsh = T.hsh;
-
-    for (uint32_t p = 0;; p++) {
-        if (__builtin_amdgcn_readfirstlane(__ballot(!done) == 0))
-            break;
-        const uint32_t nup = p < nfreeze ? p : nfreeze;
-        const double   rc  = rcp[nup];
-        const uint32_t c   = 257u + nup;
-        // All vector-memory traffic of a step is issued HERE, a whole symbol before anything
-        // waits on it: the bit buffer's refill (consumes the dword prefetched a step ago,
-        // prefetches the next) and the store of the four symbols completed by the last step.
-        // The word loaded by the previous step's refill is committed only now, so no
-        // instruction of the step that issued the load depends on it.
-        nextw = fetched;
-        {
-            const bool need = !done && bcnt <= 32;
-            if (need) {
-                bbits |= (uint64_t)__builtin_bswap32(nextw) << (32 - bcnt);
-                bcnt += 32;
-            }
-            fetched = need ? 0u : nextw;
-            if (need && rpo < rpo_end)
-                fetched = gin[rpo]; // consumed by the NEXT step's commit: a whole step to arrive
-            rpo += need ? 1u : 0u;
-        }
-        if ((p & 3) == 0 && a.aligned4 && n_out == p && p > 0) {
-            *reinterpret_cast<uint32_t *>(dst + (p - 4)) = obuf;
-            obuf   = 0;
-            stored = p;
-        }
-        if (!done) {
-            // ---- value (codec.rs:129-131) ----
-            const uint32_t R1 = (high - low) >> sh;
-            const uint32_t Vd = (W - low) >> sh;
-            const double   xd = (double)R1 + 1.0;
-            const double   cd = (double)c;
-            const double   nd = __builtin_fma((double)Vd, cd, cd - 1.0); // (Vd+1)*c - 1, exact
-            double         r  = __builtin_amdgcn_rcp(xd);
-            r                 = __builtin_fma(__builtin_fma(-xd, r, 1.0), r, r);
-            uint32_t v        = (uint32_t)(nd * (r * 0.99999999999909050530)); // (1 - 2^-40)
-            v += __builtin_fma(-(double)v, xd, nd) >= xd ? 1u : 0u;
-
-            // ---- get_symbol (adaptive_tree.rs:115-136) ----
-            const bool is_eof = v >= c - 1; // first probe: tree[256] = count - 1
-            uint32_t   rem    = v;
-            Tree<true>::Nodes nodes;
-            uint32_t   s;
-            {
-                auto val = [&](uint32_t w) { return (w >> hsh) & 0xFFFFu; };
-                // round A: levels 7, 6, 5
-                const uint32_t w128 = T.ld((128u << 7) | L);
-                const uint32_t w64 = T.ld((64u << 7) | L), w192 = T.ld((192u << 7) | L);
-                const uint32_t w32 = T.ld((32u << 7) | L), w96 = T.ld((96u << 7) | L);
-                const uint32_t w160 = T.ld((160u << 7) | L), w224 = T.ld((224u << 7) | L);
-                nodes.x[7]        = w128;
-                uint32_t t        = 128u + val(w128);
-                const bool b7     = rem >= t;
-                rem -= b7 ? t : 0u;
-                nodes.x[6]        = b7 ? w192 : w64;
-                t                 = 64u + val(nodes.x[6]);
-                const bool b6     = rem >= t;
-                rem -= b6 ? t : 0u;
-                nodes.x[5]        = b6 ? (b7 ? w224 : w96) : (b7 ? w160 : w32);
-                t                 = 32u + val(nodes.x[5]);
-                const bool b5     = rem >= t;
-                rem -= b5 ? t : 0u;
-                uint32_t i        = (b7 ? 128u : 0u) | (b6 ? 64u : 0u) | (b5 ? 32u : 0u);
-                // round B: levels 4, 3, 2 under i
-                uint32_t ib       = (i << 7) | L;
-                const uint32_t w16 = T.ld(ib + (16u << 7));
-                const uint32_t w8 = T.ld(ib + (8u << 7)), w24 = T.ld(ib + (24u << 7));
-                const uint32_t w4 = T.ld(ib + (4u << 7)), w12 = T.ld(ib + (12u << 7));
-                const uint32_t w20 = T.ld(ib + (20u << 7)), w28 = T.ld(ib + (28u << 7));
-                nodes.x[4]        = w16;
-                t                 = 16u + val(w16);
-                const bool b4     = rem >= t;
-                rem -= b4 ? t : 0u;
-                nodes.x[3]        = b4 ? w24 : w8;
-                t                 = 8u + val(nodes.x[3]);
-                const bool b3     = rem >= t;
-                rem -= b3 ? t : 0u;
-                nodes.x[2]        = b3 ? (b4 ? w28 : w12) : (b4 ? w20 : w4);
-                t                 = 4u + val(nodes.x[2]);
-                const bool b2     = rem >= t;
-                rem -= b2 ? t : 0u;
-                i |= (b4 ? 16u : 0u) | (b3 ? 8u : 0u) | (b2 ? 4u : 0u);
-                // round C: levels 1, 0 under i
-                ib                = (i << 7) | L;
-                const uint32_t w2 = T.ld(ib + (2u << 7));
-                const uint32_t w1 = T.ld(ib + (1u << 7)), w3 = T.ld(ib + (3u << 7));
-                nodes.x[1]        = w2;
-                t                 = 2u + val(w2);
-                const bool b1     = rem >= t;
-                rem -= b1 ? t : 0u;
-                nodes.x[0]        = b1 ? w3 : w1;
-                t                 = 1u + val(nodes.x[0]);
-                const bool b0     = rem >= t;
-                rem -= b0 ? t : 0u;
-                s                 = i | (b1 ? 2u : 0u) | (b0 ? 1u : 0u);
-            }
-            const uint32_t lo = v - rem; // cum(s): what the descent subtracted
-            const uint32_t hi = T.finish_high(s, nup, nodes);
-            if (p < nfreeze && !is_eof) { // update(s+1), adaptive_tree.rs:83-92
-                const uint32_t ss  = s << 7;
-                const uint32_t nsl = (s ^ 0xFFu) << hsh;
-#pragma unroll
-                for (int b = 0; b < 8; b++)
-                    (void)T.add(T.addr(ss, b), (nsl >> b) & T.inc);
-            }
-            if (is_eof) { // codec.rs:136-138
-                done = true;
-            } else if (p >= capn) {
-                st   = REDUX_OUTPUT_TOO_SMALL;
-                done = true;
-            } else {
-                const double   Y     = __builtin_fma((double)R1, rc, rc);
-                const uint32_t nlow  = low + (scale_div<false>(R1, Y, lo, c) << sh);
-                const uint32_t nhigh = low + (scale_div<false>(R1, Y, hi, c) << sh) - 1u;
-                const uint32_t xx    = nlow ^ nhigh;
-                const uint32_t k     = xx ? (uint32_t)__builtin_clz(xx) : 32u;
-                const uint32_t low2  = (uint32_t)((uint64_t)nlow << k);
-                const uint32_t ih2   = (uint32_t)((uint64_t)(~nhigh) << k);
-                const uint32_t t2    = (low2 & ih2) << 1;
-                const uint32_t j     = (uint32_t)__builtin_clz(~t2);
-                low                  = (low2 << j) & 0x7FFFFFFFu;
-                high                 = ~((ih2 << j) & 0x7FFFFFFFu);
-                const uint32_t n     = k + j;
-                consumed += n;
-                if (consumed > stream_bits) { // bitio/mod.rs:107
-                    st   = REDUX_EOF;
-                    done = true;
-                } else {
-                    // [value | next 32 bits] << k, keep the top bit, << j, put it back (codec.rs:143-157)
-                    const uint32_t nxt  = (uint32_t)(bbits >> 32);
-                    const uint64_t comb = ((uint64_t)(W >> sh) << (32 + sh)) | ((uint64_t)nxt << sh);
-                    const uint64_t c1   = comb << k;
-                    const uint64_t c2   = c1 << j;
-                    W = (((uint32_t)(c2 >> 32) & 0x7FFFFFFFu) | ((uint32_t)(c1 >> 32) & 0x80000000u)) &
-                        (0xFFFFFFFFu << sh);
-                    bbits <<= n; // bcnt may drop below 32: the refill at the top of the next step restores it
-                    bcnt -= n;
-                    if (a.aligned4)
-                        obuf |= s << (8 * (p & 3));
-                    else
-                        dst[p] = (uint8_t)s;
-                    n_out = p + 1;
-                }
-            }
-        }
-    }
-    if (live) {
-        if (a.aligned4)
-            for (uint32_t i = stored; i < n_out; i++)
-                dst[i] = (uint8_t)(obuf >> (8 * (i & 3)));
-        a.out_sizes[blk] = n_out;
-        a.status[blk]    = st;
-        if (a.in_used) { // the reader fetches whole bytes, and never past the end of the stream
-            const uint64_t used = ((uint64_t)consumed + 7) / 8;
-            a.in_used[blk]      = used < size ? used : size;
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------
-// Lock-step decoder (the default for u16 trees, count < 2^17).  Same results as k_decode and
-// k_decode_fast; what changes is the instruction count of a step, which is what a lone wave
+// Lock-step decoder (the default for u16 trees, count < 2^17).  Same results as k_decode; what changes is the instruction count of a step, which is what a lone wave
 // per SIMD pays for:
 //   * own tree layout: lane l owns dword column l; dword k of the column holds nodes 2k (low
 //     half) and 2k+1 (high half): byte address (k << 8) | 4*l.  Levels 1-7 are even nodes, so
@@ -1144,7 +906,9 @@ __device__ __forceinline__ void dec_update(uint32_t *lds, const uint32_t (&A)[8]
     }
 }
 
-// value = floor(((V - low + 1) * count - 1) / range) (codec.rs:129-131), see k_decode_fast
+// value = floor(((V - low + 1) * count - 1) / range) (codec.rs:129-131) in f64: numerator (< 2^49)
+// and range (<= 2^32) are exact; reciprocal = v_rcp_f64 + one Newton step, biased DOWN by 2^-40 so
+// the truncated product is q or q-1; one exact f64 remainder (fma) adds the 1 back.
 __device__ __forceinline__ uint32_t dec_value(double R1d, uint32_t Vd, double cd, double cdm1)
 {
     const double xd = R1d + 1.0;
@@ -2077,10 +1841,6 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         k_decode_lock<true><<<grid, 64, 0, s>>>(a);
     else if (g.u16 && !g.fixup && !force)
         k_decode_lock<false><<<grid, 64, 0, s>>>(a);
-    else if (g.u16 && !g.fixup && !(force && !strcmp(force, "generic")) && p->code_bits == 32)
-        k_decode_fast<true><<<grid, 64, 0, s>>>(a);
-    else if (g.u16 && !g.fixup && !(force && !strcmp(force, "generic")))
-        k_decode_fast<false><<<grid, 64, 0, s>>>(a);
     else if (g.u16 && !g.fixup)
         k_decode<true, false><<<grid, 64, 0, s>>>(a);
     else if (g.u16)
