@@ -325,6 +325,9 @@ struct ChunkQueue {
     }
 };
 
+#ifndef REDUX_KEEP8
+#define REDUX_KEEP8 1
+#endif
 template <bool UPD>
 __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, uint32_t lane, const uint4 cur,
                                             uint32_t p, uint32_t nfreeze)
@@ -342,14 +345,22 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
     for (int i = 0; i < 16; i++) {
         const uint32_t s   = sym(i);
         const uint32_t nup = UPD ? p + i : nfreeze;
-        if (i + D < 16) {
+        // At the hand-over in the middle of the chunk the next symbol's eight LDS ops are issued
+        // AFTER this symbol's ring write and stay in flight across the barrier (LDS ops of a wave
+        // complete in order, so lgkmcnt <= 8 means the ring half is written).
+        const bool late = REDUX_KEEP8 && i == 7;
+        if (i + D < 16 && !late) {
             q[D] = T.template issue<UPD>(sym(i + D), true);
             __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t lo, hi;
         T.finish(s, nup, q[0], lo, hi);
         ring[i * 64 + lane] = make_uint2(lo, hi);
-        if ((i & 7) == 7)
+        if (late) {
+            __builtin_amdgcn_sched_barrier(0);
+            q[D] = T.template issue<UPD>(sym(i + D), true);
+            asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+        } else if ((i & 7) == 7)
             pair_barrier();
 #pragma unroll
         for (int d = 0; d < D; d++)

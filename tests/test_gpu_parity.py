@@ -199,6 +199,60 @@ def test_error_paths(rx):
         rx.compress_blocks(data, BLOCK, (8, 24, 40))
 
 
+def _oracle_decode_raw(stream, cap, params):
+    """ox_decompress without raising: (status, bytes written before the status was decided)."""
+    import ctypes as C
+    a = np.ascontiguousarray(np.frombuffer(bytes(stream), dtype=np.uint8))
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    bi, bo = C.c_uint64(), C.c_uint64()
+    st = ox.lib().ox_decompress(a.ctypes.data if len(a) else None, len(a), out.ctypes.data, cap, params[0], params[1],
+                                params[2], ox.TREE, C.byref(bi), C.byref(bo))
+    return st, out[: bo.value].tobytes()
+
+
+@pytest.mark.parametrize("params", [(8, 30, 32), (8, 14, 16)])
+def test_decode_fuzz_matches_oracle(rx, params):
+    """Garbage, corrupted, truncated and over-long streams: status, decoded length and decoded
+    bytes of every block equal the CPU restatement's (Eof where read_bits fails, bitio/mod.rs:107;
+    a symbol is only emitted once its renormalisation has its bits, codec.rs:140-158).  Also the
+    decoder's memory-safety net: streams of every length and alignment, lanes finishing at
+    different steps, a last stream that ends exactly at the end of the buffer."""
+    rnd = np.random.default_rng(20260311)
+    cap = 2048
+    streams = []
+    for n in list(range(0, 24)) + [int(x) for x in rnd.integers(24, 700, 60)]:
+        streams.append(rnd.integers(0, 256, n, dtype=np.uint8).tobytes())           # garbage
+    streams += [b"\x00" * n for n in (1, 4, 5, 64, 300)] + [b"\xff" * n for n in (1, 4, 7, 64, 300)]
+    for i in range(70):                                                                # damaged valid streams
+        kind = i % 5
+        src = rnd.integers(0, (4, 256, 16, 256, 2)[kind], int(rnd.integers(0, 1500)), dtype=np.uint8).tobytes()
+        good, _ = ox.compress(src, params)
+        b = bytearray(good)
+        if kind == 0 and b:
+            b[int(rnd.integers(0, len(b)))] ^= 1 << int(rnd.integers(0, 8))         # one flipped bit
+        elif kind == 1:
+            b = b[: int(rnd.integers(0, len(b) + 1))]                                 # truncated
+        elif kind == 2:
+            b += rnd.integers(0, 256, int(rnd.integers(1, 9)), dtype=np.uint8).tobytes()  # trailing bytes
+        elif kind == 3 and len(b) > 8:
+            j = int(rnd.integers(0, len(b) - 4))
+            b[j: j + 4] = rnd.integers(0, 256, 4, dtype=np.uint8).tobytes()         # a damaged dword
+        streams.append(bytes(b))                                                      # kind 4: intact
+    offs = np.zeros(len(streams) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in streams])
+    dense = np.frombuffer(b"".join(streams), dtype=np.uint8)
+    dec, sizes, status = rx.decompress_blocks(dense, offs, cap, params, check=False)
+    seen = set()
+    for b, stream in enumerate(streams):
+        st, want = _oracle_decode_raw(stream, cap, params)
+        st = 4 if st == 3 else st  # the oracle's writer fails with IoError where the block capacity ends
+        seen.add(st)
+        assert int(status[b]) == st, (b, len(stream), int(status[b]), st)
+        assert int(sizes[b]) == len(want), (b, len(stream), int(sizes[b]), len(want))
+        assert dec[b * cap: b * cap + len(want)].tobytes() == want, (b, len(stream))
+    assert {0, 1, 4} <= seen  # the mix really exercises Ok, Eof and capacity overflow
+
+
 def test_generators_match_host_definition(rx):
     import torch
     n = 1 << 16
