@@ -166,7 +166,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_encode_pair<false> (u16 tree, model wave + coder wave)",
+            "kernel": "k_encode_pair<false, true> (u16 tree, model wave + coder wave, code_bits 32)",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
