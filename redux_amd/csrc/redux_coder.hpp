@@ -96,10 +96,10 @@ struct Tree {
         return __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + byte_addr), v,
                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // node address for level b of symbol s: one v_and_or_b32
+    // node address for level b of symbol s: one v_and_or_b32 (level 7 is always node 128: none)
     __device__ __forceinline__ uint32_t addr(uint32_t ss, int b) const
     {
-        return (ss & (((0xFFu << b) & 0xFFu) << kShift)) | A[b];
+        return b == 7 ? A[7] : ((ss & (((0xFFu << b) & 0xFFu) << kShift)) | A[b]);
     }
     // this lane's value of the node at byte_addr (decode descent)
     __device__ __forceinline__ uint32_t node(uint32_t byte_addr) const
