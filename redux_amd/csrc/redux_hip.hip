@@ -1153,21 +1153,22 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
 #endif
     if (aligned4) {
         double cdm1 = 256.0, cd = 257.0;
-        // the group's four reciprocals are loaded a group ahead: one scalar load per group, and
-        // its latency never sits in front of an LDS wait (SMEM and LDS share lgkmcnt)
-        double rcg[4], rcn[4];
-#pragma unroll
-        for (int K = 0; K < 4; K++)
-            rcg[K] = rcp[K];
+        // The group's four reciprocals are loaded a group ahead with VECTOR loads (every lane the
+        // same 32 bytes), behind the ring's chunk request: their latency is covered by the one
+        // vmcnt wait of the next group.  A scalar load would share lgkmcnt with the LDS, return
+        // out of order and so sit in front of the next LDS wait wherever it is issued.
+        typedef double f64x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) f64x4 *grc4;
+        const grc4 rcv = (grc4)(uintptr_t)a.rc; // 256-byte aligned workspace, p a multiple of 4
+        f64x4      rcg = rcv[0], rcn;
+        asm volatile("" : "+v"(rcg)); // arrived before the loop: no in-loop wait inherits this load
         for (; p + 4 <= pfast; p += 4) {
             if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
                 break;
-#pragma unroll
-            for (int K = 0; K < 4; K++)
-                rcn[K] = rcp[p + 4 + K]; // the table has 32 entries of slack (geometry())
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
             REDUX_DEC_REQUEST
+            rcn = rcv[(p >> 2) + 1]; // the table has 32 entries of slack (geometry())
 #pragma unroll
             for (int K = 0; K < 4; K++) {
                 const double   rc = rcg[K];
@@ -1249,9 +1250,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
                 cd += 1.0;
                 DEC_STAMP(6, S.low + S.W)
             }
-#pragma unroll
-            for (int K = 0; K < 4; K++)
-                rcg[K] = rcn[K];
+            rcg = rcn;
         }
     }
 #ifdef REDUX_DEC_STAMPS
