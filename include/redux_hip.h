@@ -130,6 +130,12 @@ const uint32_t *redux_zipf_thresholds(void);
 /* Library / build identification: "redux_hip <version> gfx950". */
 const char *redux_version(void);
 
+/* Diagnostic, used by the parity tests only: *max_err = max over the integers x in [lo, hi] of
+ * |v_rcp_f64(x) * x - 1| evaluated on the device.  The decoder's code-value division
+ * (codec.rs:131) multiplies by the raw hardware reciprocal of `range` (an integer in [1, 2^32])
+ * and relies on this error staying below 2^-24 over that whole range. */
+int redux_debug_rcp_check(uint64_t lo, uint64_t hi, double *max_err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -917,18 +917,38 @@ __device__ __forceinline__ void dec_update(uint32_t *lds, const uint32_t (&A)[8]
     }
 }
 
-// value = floor(((V - low + 1) * count - 1) / range) (codec.rs:129-131) in f64: numerator (< 2^49)
-// and range (<= 2^32) are exact; reciprocal = v_rcp_f64 + one Newton step, biased DOWN by 2^-40 so
-// the truncated product is q or q-1; one exact f64 remainder (fma) adds the 1 back.
+// value = floor(((V - low + 1) * count - 1) / range) (codec.rs:129-131) in f64.  Numerator nd
+// (< 2^49) and range xd (an integer in [1, 2^32]) are exact.  r' = v_rcp_f64(xd) * (1 - 2^-22):
+// the raw v_rcp_f64 of gfx950 is within 2^-24 (measured: 2^-24.4) of 1/xd for EVERY integer xd in [1, 2^32]
+// (checked exhaustively on the device by redux_debug_rcp_check, tests/test_gpu_parity.py), so
+// (1 - 2^-21)/xd <= r' <= 1/xd and, the quotient being < 2^17.1, the truncated product is q or
+// q - 1; one exact f64 remainder (fma; v * xd < 2^50) adds the 1 back.
 __device__ __forceinline__ uint32_t dec_value(double R1d, uint32_t Vd, double cd, double cdm1)
 {
     const double xd = R1d + 1.0;
     const double nd = __builtin_fma((double)Vd, cd, cdm1); // (Vd+1)*c - 1, exact (< 2^49)
-    double       r  = __builtin_amdgcn_rcp(xd);
-    r               = __builtin_fma(__builtin_fma(-xd, r, 1.0), r, r);
-    uint32_t v      = (uint32_t)(nd * (r * 0.99999999999909050530)); // (1 - 2^-40): q or q-1
+#ifdef REDUX_DEC_NEWTON // the older form: one Newton step, bias 2^-40
+    double r = __builtin_amdgcn_rcp(xd);
+    r        = __builtin_fma(__builtin_fma(-xd, r, 1.0), r, r);
+    uint32_t v = (uint32_t)(nd * (r * 0.99999999999909050530));
+#else
+    uint32_t v = (uint32_t)(nd * (__builtin_amdgcn_rcp(xd) * 0.99999976158142089844)); // 1 - 2^-22
+#endif
     v += __builtin_fma(-(double)v, xd, nd) >= xd ? 1u : 0u;
     return v;
+}
+
+// exhaustive check behind dec_value: max over all integers x in [lo, hi] of |rcp(x) * x - 1|, as
+// the f64 bit pattern of the maximum (positive doubles order like their bits)
+__global__ void k_rcp_check(uint64_t lo, uint64_t hi, unsigned long long *max_bits)
+{
+    double m = 0.0;
+    for (uint64_t x = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x <= hi; x += (uint64_t)gridDim.x * blockDim.x) {
+        const double xd = (double)x;
+        const double e  = __builtin_fabs(__builtin_fma(__builtin_amdgcn_rcp(xd), xd, -1.0));
+        m               = e > m ? e : m;
+    }
+    atomicMax(max_bits, (unsigned long long)__double_as_longlong(m));
 }
 
 struct DecLane {
@@ -937,8 +957,10 @@ struct DecLane {
     uint64_t bbits;      // upcoming stream bits, left-aligned
     uint32_t bcnt;       // how many of them are valid
     uint32_t consumed;   // stream bits pulled so far
-    uint32_t obuf, n_out;
+    uint32_t obuf;
+    uint32_t n_out;      // symbols emitted: set when the block finishes (a live lane has emitted one per step)
     uint32_t dflag;      // 0x80000000 once the block is finished (EOF symbol or error)
+    uint32_t sbits;      // stream length in bits while the block is live, 0 once it is finished
     int32_t  st;
 };
 
@@ -955,11 +977,15 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
         return;
     if ((int32_t)f.eofq < 0) { // codec.rs:136-138: returns before any renormalisation
         S.dflag = 0x80000000u;
+        S.sbits = 0;
+        S.n_out = p;
         return;
     }
     if (!room) {
         S.st    = REDUX_OUTPUT_TOO_SMALL;
         S.dflag = 0x80000000u;
+        S.sbits = 0;
+        S.n_out = p;
         return;
     }
     if (may_update)
@@ -980,6 +1006,8 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
     if (S.consumed > stream_bits) { // read_bits would return Err(Eof) (bitio/mod.rs:107)
         S.st    = REDUX_EOF;
         S.dflag = 0x80000000u;
+        S.sbits = 0;
+        S.n_out = p;
         return;
     }
     // [value | next 32 bits] << k, keep the top bit, << j, put it back (codec.rs:143-157)
@@ -994,7 +1022,6 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
         S.obuf |= f.s << (8 * (p & 3));
     else
         dst[p] = (uint8_t)f.s;
-    S.n_out = p + 1;
 }
 
 template <bool CB32>
@@ -1094,6 +1121,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
         S.st    = REDUX_EOF;
         S.dflag = 0x80000000u;
     }
+    S.sbits = (int32_t)S.dflag < 0 ? 0u : stream_bits;
     S.n_out = 0;
     S.obuf  = 0;
     uint32_t stored = 0;
@@ -1118,7 +1146,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
     if (pend)                                                                                                          \
         ring_write(pend_chunk, ldq.x, ldq.y, ldq.z, ldq.w);
 #define REDUX_DEC_STORE                                                                                                \
-    if (aligned4 && S.n_out == p && p > stored) {                                                                      \
+    if (aligned4 && (int32_t)S.dflag >= 0 && p > stored) { /* a live lane has emitted p symbols */                  \
         *reinterpret_cast<uint32_t *>(dst + (p - 4)) = S.obuf;                                                         \
         S.obuf = 0;                                                                                                    \
         stored = p;                                                                                                    \
@@ -1227,7 +1255,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
                 const uint32_t j     = (uint32_t)__builtin_clz(~t2);
                 const uint32_t n     = k + j;
                 const uint32_t cons2 = S.consumed + n;
-                const uint32_t e     = f.eofq | k | (stream_bits - cons2) | S.dflag;
+                const uint32_t e     = f.eofq | k | (S.sbits - cons2); // sbits is 0 for a finished lane, cons2 > 0
                 DEC_STAMP(5, e)
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)e < 0) == 0, 1)) {
                     dec_update(lds, A, T, f.s);
@@ -1242,7 +1270,6 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
                     S.bbits <<= n;
                     S.bcnt -= n;
                     S.obuf |= f.s << (8 * K);
-                    S.n_out = p + K + 1;
                 } else {
                     dec_commit_careful<CB32>(S, T, f, lds, A, R1, R1d, rc, c, sh, stream_bits, p + K, true, true, true, dst);
                 }
@@ -1869,6 +1896,19 @@ extern "C" int redux_debug_dec_stamps(uint64_t *out8)
     return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dec_ts), 64);
 }
 #endif
+
+// Diagnostic (tests only): max |v_rcp_f64(x) * x - 1| over the integers lo..hi, on the device.
+int redux_debug_rcp_check(uint64_t lo, uint64_t hi, double *max_err)
+{
+    unsigned long long *d = nullptr, h = 0;
+    HIP_TRY(hipMalloc(&d, 8));
+    HIP_TRY(hipMemset(d, 0, 8));
+    k_rcp_check<<<4096, 256>>>(lo, hi, d);
+    HIP_TRY(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d));
+    memcpy(max_err, &h, 8);
+    return REDUX_OK;
+}
 
 int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void *d_in_offsets, uint64_t nblocks,
                             uint32_t block_size, void *d_out, uint64_t out_cap, void *d_out_sizes,

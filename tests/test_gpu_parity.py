@@ -253,6 +253,18 @@ def test_decode_fuzz_matches_oracle(rx, params):
     assert {0, 1, 4} <= seen  # the mix really exercises Ok, Eof and capacity overflow
 
 
+def test_rcp_f64_error_bound_exhaustive(rx):
+    """dec_value (codec.rs:131) multiplies by the raw v_rcp_f64 of `range`, an integer in
+    [1, 2^32]; its proof needs |rcp(x)*x - 1| < 2^-24 for every such x.  All 2^32 of them."""
+    import ctypes as C
+    from redux_amd import _lib
+    err = C.c_double()
+    assert _lib.lib().redux_debug_rcp_check(1, 1 << 32, C.byref(err)) == 0
+    assert 0.0 < err.value < 2.0 ** -24, err.value
+    print("max |rcp(x)*x-1| over [1, 2^32]:", err.value)
+
+
+
 def test_generators_match_host_definition(rx):
     import torch
     n = 1 << 16
