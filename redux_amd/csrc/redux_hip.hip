@@ -1365,13 +1365,43 @@ __global__ void __launch_bounds__(1024) k_scan_sizes(ScanArgs a)
     uint64_t       sum = 0;
     uint32_t       nb  = 0;
     uint64_t       fb  = ~0ull;
-    for (uint64_t b = b0; b < b1; b++) {
-        sum += a.sizes[b];
-        const int32_t st = a.status[b];
-        if (st != REDUX_OK) {
-            nb++;
-            if (fb == ~0ull)
-                fb = (b << 8) | (uint32_t)st;
+    // Up to 64 blocks per thread in whole quads (the 65,536-block configuration): the sizes stay
+    // in registers between the two passes and move as 16-byte loads, all in flight at once,
+    // instead of 3 x 64 dependent 4-byte accesses per thread.
+    const bool quads = per <= 64 && (per & 3) == 0 && (a.nblocks % per) == 0 &&
+                       ((((uintptr_t)a.sizes) | ((uintptr_t)a.status) | ((uintptr_t)a.offsets)) & 15) == 0;
+    uint4      sz[16];
+    if (quads) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(a.sizes + b0);
+        const int4  *t4 = reinterpret_cast<const int4 *>(a.status + b0);
+        int4         stv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool in = b0 + 4 * i < b1;
+            sz[i]  = in ? s4[i] : make_uint4(0, 0, 0, 0);
+            stv[i] = in ? t4[i] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            sum += (uint64_t)sz[i].x + sz[i].y + sz[i].z + sz[i].w;
+            const int32_t st4[4] = {stv[i].x, stv[i].y, stv[i].z, stv[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (st4[k] != REDUX_OK) {
+                    nb++;
+                    if (fb == ~0ull)
+                        fb = ((b0 + 4 * i + k) << 8) | (uint32_t)st4[k];
+                }
+        }
+    } else {
+        for (uint64_t b = b0; b < b1; b++) {
+            sum += a.sizes[b];
+            const int32_t st = a.status[b];
+            if (st != REDUX_OK) {
+                nb++;
+                if (fb == ~0ull)
+                    fb = (b << 8) | (uint32_t)st;
+            }
         }
     }
     part[tid] = sum;
@@ -1388,9 +1418,21 @@ __global__ void __launch_bounds__(1024) k_scan_sizes(ScanArgs a)
         __syncthreads();
     }
     uint64_t run = tid ? part[tid - 1] : 0;
-    for (uint64_t b = b0; b < b1; b++) {
-        a.offsets[b] = run;
-        run += a.sizes[b];
+    if (quads) {
+        ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(a.offsets + b0); // b0 is a multiple of 4: 16-byte aligned
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (b0 + 4 * i < b1) {
+                const uint64_t r1 = run + sz[i].x, r2 = r1 + sz[i].y, r3 = r2 + sz[i].z;
+                o2[2 * i]     = make_ulonglong2(run, r1);
+                o2[2 * i + 1] = make_ulonglong2(r2, r3);
+                run           = r3 + sz[i].w;
+            }
+    } else {
+        for (uint64_t b = b0; b < b1; b++) {
+            a.offsets[b] = run;
+            run += a.sizes[b];
+        }
     }
     if (tid == 1023)
         a.offsets[a.nblocks] = part[1023];
