@@ -10,6 +10,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC redux_hip.hip -o libredux_hip.so
 #include "redux_coder.hpp"
+#include "redux_any.hpp"
 
 #include "../../include/redux_hip.h"
 
@@ -1579,6 +1580,68 @@ __global__ void k_gen_zipf(uint8_t *out, uint64_t len, uint64_t first, uint64_t 
 }
 
 // ======================================================================================
+// general parameters (redux_any.hpp): one lane per block, tree in the workspace
+// ======================================================================================
+struct AnyEncArgs {
+    const uint8_t *in;
+    uint64_t       in_len, nblocks;
+    uint8_t       *slots;
+    uint64_t       slot_bytes;
+    uint32_t      *sizes;
+    int32_t       *status;
+    uint32_t      *trees;
+    uint64_t       tree_words; // u32 entries per block
+    uint32_t       block_size, slot_cap;
+    uint32_t       sb, fb, cb;
+};
+
+__global__ void __launch_bounds__(64) k_encode_any(AnyEncArgs a)
+{
+    const uint64_t blk = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (blk >= a.nblocks)
+        return;
+    const uint64_t o0  = blk * a.block_size;
+    const uint64_t rem = a.in_len > o0 ? a.in_len - o0 : 0;
+    const uint64_t len = rem < a.block_size ? rem : a.block_size;
+    const any::Params P = any::make_params(a.sb, a.fb, a.cb);
+    uint64_t  bi, bo;
+    const int st = any::compress_stream(P, a.trees + blk * a.tree_words, a.in + o0, len, a.slots + blk * a.slot_bytes,
+                                        a.slot_cap, bi, bo);
+    a.sizes[blk]  = (uint32_t)bo;
+    a.status[blk] = st;
+}
+
+struct AnyDecArgs {
+    const uint8_t  *in;
+    const uint64_t *in_offsets;
+    uint64_t        nblocks;
+    uint8_t        *out;
+    uint32_t       *out_sizes;
+    int32_t        *status;
+    uint64_t       *in_used;
+    uint32_t       *trees;
+    uint64_t        tree_words;
+    uint32_t        block_size;
+    uint32_t        sb, fb, cb;
+};
+
+__global__ void __launch_bounds__(64) k_decode_any(AnyDecArgs a)
+{
+    const uint64_t blk = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (blk >= a.nblocks)
+        return;
+    const uint64_t o0 = a.in_offsets[blk], o1 = a.in_offsets[blk + 1];
+    const any::Params P = any::make_params(a.sb, a.fb, a.cb);
+    uint64_t  bi, bo;
+    const int st = any::decompress_stream(P, a.trees + blk * a.tree_words, a.in + o0, o1 - o0,
+                                          a.out + blk * (uint64_t)a.block_size, a.block_size, bi, bo);
+    a.out_sizes[blk] = (uint32_t)bo;
+    a.status[blk]    = st;
+    if (a.in_used)
+        a.in_used[blk] = bi;
+}
+
+// ======================================================================================
 // host side of the ABI
 // ======================================================================================
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
@@ -1590,8 +1653,10 @@ struct Geometry {
     uint32_t rc_n;       // reciprocal table entries
     uint32_t nfreeze;
     bool     u16, fixup;
+    bool     any;        // general-parameter path (redux_any.hpp): symbol_bits != 8 or code_bits > 32
+    uint64_t tree_bytes; // any: per-block tree in the workspace
     // workspace layout (encode)
-    uint64_t off_rc, off_sizes, off_slots, total;
+    uint64_t off_rc, off_sizes, off_slots, off_trees, total;
 };
 
 static int check_params(const redux_params *p)
@@ -1601,18 +1666,31 @@ static int check_params(const redux_params *p)
     const int st = redux_params_check(p->symbol_bits, p->freq_bits, p->code_bits);
     if (st != REDUX_OK)
         return st;
-    if (p->symbol_bits != 8 || p->code_bits > 32)
+    if (p->symbol_bits > 16) // a tree of 2^symbol_bits + 2 entries per block
         return REDUX_UNSUPPORTED;
     return REDUX_OK;
 }
 
+static bool is_any(const redux_params *p) { return p->symbol_bits != 8 || p->code_bits > 32; }
+
 static uint64_t slot_cap_for(const redux_params *p, uint32_t block_size)
 {
+    const uint64_t freq_max = (1ull << p->freq_bits) - 1;
+    if (is_any(p)) {
+        // General parameters: a symbol of frequency >= 1 out of count <= min(freq_max, K + n)
+        // costs at most ceil(log2 count) bits, + 1 for the truncation of codec.rs:59-60, + 1 spare.
+        const uint64_t K = (1ull << p->symbol_bits) + 1;
+        const uint64_t n = (uint64_t)block_size * 8 / p->symbol_bits + 1; // symbols incl. EOF
+        uint32_t       lg = 0;
+        while ((1ull << lg) < K + n)
+            lg++;
+        const uint64_t per = (lg < p->freq_bits ? lg : p->freq_bits) + 2;
+        return n * per / 8 + p->code_bits / 8 + 64;
+    }
     // Worst case of one block's stream.  While the model never freezes inside a block the
     // adaptive code length is <= 8 bits/symbol + O(256 log N) and the integer truncation of
     // codec.rs:59-60 loses < 1 bit/symbol: 9 bits/symbol.  Once frozen (count == freq_max) a
     // symbol of frequency 1 costs up to freq_bits + 1 bits.
-    const uint64_t freq_max = (1ull << p->freq_bits) - 1;
     const uint64_t n        = block_size;
     const bool     freezes  = 257ull + n > freq_max;
     const uint64_t bits     = freezes ? n * (p->freq_bits + 2) : n * 9;
@@ -1640,10 +1718,18 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.u16   = block_size <= 65536;
     g.fixup = (257ull + (uint64_t)(g.rc_n - 1)) >= (1ull << 17);
     g.rc_n += 32; // slack: both coders load their reciprocals a group / a chunk ahead without clamping
+    g.any = is_any(p);
+    if (g.any) { // no reciprocal table; one tree of 2^symbol_bits + 2 u32 per block
+        g.rc_n       = 0;
+        g.u16        = false;
+        g.fixup      = true;
+        g.tree_bytes = align_up(((1ull << p->symbol_bits) + 2) * 4, 256);
+    }
     g.off_rc    = 0;
     g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
     g.off_slots = align_up(g.off_sizes + g.nblocks * 4, 256);
-    g.total     = g.off_slots + (g.nblocks + 1) * g.slot_bytes; // +1: spare slot for dead lanes
+    g.off_trees = align_up(g.off_slots + (g.nblocks + 1) * g.slot_bytes, 256); // +1: spare slot for dead lanes
+    g.total     = g.off_trees + g.nblocks * g.tree_bytes;
     return g;
 }
 
@@ -1718,6 +1804,25 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
         return REDUX_INVALID_INPUT;
     hipStream_t s  = (hipStream_t)stream;
     uint8_t    *ws = (uint8_t *)d_workspace;
+
+    if (g.any) {
+        AnyEncArgs aa;
+        aa.in         = (const uint8_t *)d_in;
+        aa.in_len     = in_len;
+        aa.nblocks    = g.nblocks;
+        aa.slots      = ws + g.off_slots;
+        aa.slot_bytes = g.slot_bytes;
+        aa.sizes      = (uint32_t *)(ws + g.off_sizes);
+        aa.status     = (int32_t *)d_block_status;
+        aa.trees      = (uint32_t *)(ws + g.off_trees);
+        aa.tree_words = g.tree_bytes / 4;
+        aa.block_size = block_size;
+        aa.slot_cap   = g.slot_cap;
+        aa.sb = p->symbol_bits; aa.fb = p->freq_bits; aa.cb = p->code_bits;
+        k_encode_any<<<(uint32_t)((g.nblocks + 63) / 64), 64, 0, s>>>(aa);
+        HIP_TRY(hipGetLastError());
+        return REDUX_OK;
+    }
 
     k_fill_rc<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)(ws + g.off_rc), g.rc_n);
 
@@ -1873,10 +1978,11 @@ int redux_compress(const redux_params *p, const uint8_t *in, uint64_t in_len, ui
 
 uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, uint32_t block_size)
 {
-    (void)nblocks;
     if (check_params(p) != REDUX_OK || block_size == 0)
         return 0;
     const Geometry g = geometry(p, block_size, block_size);
+    if (g.any)
+        return (nblocks ? nblocks : 1) * g.tree_bytes;
     return align_up((uint64_t)g.rc_n * 8, 256);
 }
 
@@ -1897,9 +2003,28 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     if (out_cap < nblocks * (uint64_t)block_size)
         return REDUX_OUTPUT_TOO_SMALL;
     const Geometry g = geometry(p, block_size, block_size);
-    if (workspace_bytes < align_up((uint64_t)g.rc_n * 8, 256))
+    if (workspace_bytes < redux_decode_workspace_bytes(p, nblocks, block_size))
         return REDUX_OUTPUT_TOO_SMALL;
     hipStream_t s = (hipStream_t)stream;
+    if (g.any) {
+        AnyDecArgs aa;
+        aa.in         = (const uint8_t *)d_in;
+        aa.in_offsets = (const uint64_t *)d_in_offsets;
+        aa.nblocks    = nblocks;
+        aa.out        = (uint8_t *)d_out;
+        aa.out_sizes  = (uint32_t *)d_out_sizes;
+        aa.status     = (int32_t *)d_block_status;
+        aa.in_used    = (uint64_t *)d_in_used;
+        aa.trees      = (uint32_t *)d_workspace;
+        aa.tree_words = g.tree_bytes / 4;
+        aa.block_size = block_size;
+        aa.sb = p->symbol_bits; aa.fb = p->freq_bits; aa.cb = p->code_bits;
+        k_decode_any<<<(uint32_t)((nblocks + 63) / 64), 64, 0, s>>>(aa);
+        if (d_summary)
+            k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
+        HIP_TRY(hipGetLastError());
+        return REDUX_OK;
+    }
     k_fill_rc<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)d_workspace, g.rc_n);
     DecArgs a;
     a.in         = (const uint8_t *)d_in;

@@ -46,9 +46,13 @@ def test_device_supports():
     L = _lib.lib()
     assert L.redux_device_supports(C.byref(_lib.Params(8, 30, 32))) == _lib.OK
     assert L.redux_device_supports(C.byref(_lib.Params(8, 14, 16))) == _lib.OK
-    assert L.redux_device_supports(C.byref(_lib.Params(4, 10, 16))) == _lib.UNSUPPORTED
-    assert L.redux_device_supports(C.byref(_lib.Params(12, 14, 16))) == _lib.UNSUPPORTED
-    assert L.redux_device_supports(C.byref(_lib.Params(8, 24, 40))) == _lib.UNSUPPORTED
+    # general parameters run on the one-lane-per-block path (redux_any.hpp) ...
+    assert L.redux_device_supports(C.byref(_lib.Params(4, 10, 16))) == _lib.OK
+    assert L.redux_device_supports(C.byref(_lib.Params(12, 14, 16))) == _lib.OK
+    assert L.redux_device_supports(C.byref(_lib.Params(8, 24, 40))) == _lib.OK
+    assert L.redux_device_supports(C.byref(_lib.Params(16, 18, 46))) == _lib.OK
+    # ... up to 16-bit symbols (a tree of 2^symbol_bits + 2 entries per block)
+    assert L.redux_device_supports(C.byref(_lib.Params(17, 19, 21))) == _lib.UNSUPPORTED
     assert L.redux_device_supports(C.byref(_lib.Params(8, 9, 16))) == _lib.INVALID_INPUT
 
 

@@ -194,9 +194,7 @@ def test_error_paths(rx):
     with pytest.raises(rx.InvalidInput):
         rx.compress_blocks(data, BLOCK, (8, 9, 16))
     with pytest.raises(rx.Unsupported):
-        rx.compress_blocks(data, BLOCK, (4, 10, 16))
-    with pytest.raises(rx.Unsupported):
-        rx.compress_blocks(data, BLOCK, (8, 24, 40))
+        rx.compress_blocks(data, BLOCK, (17, 19, 21))
 
 
 def _oracle_decode_raw(stream, cap, params):
@@ -251,6 +249,48 @@ def test_decode_fuzz_matches_oracle(rx, params):
         assert int(sizes[b]) == len(want), (b, len(stream), int(sizes[b]), len(want))
         assert dec[b * cap: b * cap + len(want)].tobytes() == want, (b, len(stream))
     assert {0, 1, 4} <= seen  # the mix really exercises Ok, Eof and capacity overflow
+
+
+ANY_PARAMS = [(4, 10, 16), (12, 14, 16), (8, 24, 40), (1, 3, 5), (16, 18, 20), (2, 30, 34), (8, 30, 33),
+              (12, 20, 44), (7, 9, 55), (3, 31, 33), (8, 10, 12)]
+
+
+@pytest.mark.parametrize("params", ANY_PARAMS)
+def test_general_parameters_match_oracle(rx, params):
+    """SURVEY 8(f).3: every triple Parameters::new accepts (symbol_bits <= 16) on the device --
+    4-/12-/16-bit symbols, code_bits > 32, models that freeze inside a block ((8, 10, 12): freq_max
+    1023).  Streams bit-exact with the oracle, decode equal to the oracle's decode (for symbol
+    widths that do not divide the input the reference drops the trailing bits, lib.rs:113-120)."""
+    rnd = np.random.default_rng(sum(params))
+    for bs, n, hi in ((1000, 7013, 256), (4096, 3 * 4096, 4), (333, 2000, 256)):
+        data = rnd.integers(0, hi, n, dtype=np.uint8).tobytes()
+        out, offs, st = rx.compress_blocks(data, bs, params)
+        want, _ = ox.compress_blocks(data, bs, params)
+        got = split(out, offs)
+        assert len(got) == len(want)
+        for b, (g, w) in enumerate(zip(got, want)):
+            assert g == w, (params, bs, b, len(g), len(w))
+        dec, sizes, status = rx.decompress_blocks(out, offs, bs, params)
+        for b, w in enumerate(want):
+            stw, outw = _oracle_decode_raw(w, bs, params)
+            assert stw == 0 and int(status[b]) == 0
+            assert dec[b * bs: b * bs + int(sizes[b])].tobytes() == outw, (params, bs, b)
+    # whole-stream drop-ins (one block of any length) and the reader/writer byte counts of lib.rs:108,119
+    data = rnd.integers(0, 256, 5000, dtype=np.uint8).tobytes()
+    o = io.BytesIO()
+    cin, cout = rx.compress(io.BytesIO(data), o, rx.AdaptiveTreeModel(rx.Parameters(*params)))
+    w, (wi, wo) = ox.compress(data, params)
+    assert o.getvalue() == w and (cin, cout) == (wi, wo)
+    # damaged streams: status and partial output as the oracle
+    bad = [w[: len(w) // 2], w[:3], b"", bytes(rnd.integers(0, 256, 300, dtype=np.uint8)), w + b"\x00\x01"]
+    offs2 = np.zeros(len(bad) + 1, dtype=np.uint64)
+    offs2[1:] = np.cumsum([len(x) for x in bad])
+    dec, sizes, status = rx.decompress_blocks(np.frombuffer(b"".join(bad), dtype=np.uint8), offs2, 8192, params, check=False)
+    for b, stream in enumerate(bad):
+        stw, outw = _oracle_decode_raw(stream, 8192, params)
+        stw = 4 if stw == 3 else stw
+        assert int(status[b]) == stw, (params, b, int(status[b]), stw)
+        assert dec[b * 8192: b * 8192 + int(sizes[b])].tobytes() == outw, (params, b)
 
 
 def test_rcp_f64_error_bound_exhaustive(rx):
