@@ -45,9 +45,9 @@ enum {
 /* The three integers of model::Parameters::new (src/model/mod.rs:63); the library derives
  * the other eight fields (mod.rs:67-79) itself. */
 typedef struct redux_params {
-    uint32_t symbol_bits; /* 8 on the device path */
+    uint32_t symbol_bits; /* 1..16 on the device (8: fast kernels) */
     uint32_t freq_bits;
-    uint32_t code_bits;   /* <= 32 on the device path */
+    uint32_t code_bits;   /* <= 32 with symbol_bits 8: fast kernels; else general path */
 } redux_params;
 
 /* model::Parameters::new validation, src/model/mod.rs:64: OK or INVALID_INPUT. */
