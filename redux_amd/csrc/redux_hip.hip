@@ -839,8 +839,9 @@ struct DecFound {
 // lock-step decoder wave is alone on its SIMD and the four waves of a CU share one LDS
 // pipeline: 8 cycles per ds_read_b32 and 16 per ds_add, tools/ubench/lone.hip.)
 struct DecTop {
-    uint32_t n128, n64, n192, n32, n96, n160, n224; // increments, like the LDS nodes
+    uint32_t n128, n64, n192, n32, n96, n160, n224; // full tree values (lowbit + increments): u32, no overflow to think about
 };
+__device__ __forceinline__ DecTop dec_top_new() { return {128u, 64u, 64u, 32u, 32u, 32u, 32u}; }
 
 // get_symbol (adaptive_tree.rs:115-136) + the high end of get_frequency (:105-113), layout above.
 // Safe for any v (lanes that are already done run it on garbage): every address stays inside
@@ -852,41 +853,37 @@ __device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, 
     uint32_t q = ~v, hq = q + (c - 1u), bits = 0, q2;
     DecFound f;
     f.eofq = hq;
-#define REDUX_DEC_LEVEL(val, base)                                                                                     \
-    q2   = q + (val) + (base);                                                                                         \
+#define REDUX_DEC_LEVEL(t)                                                                                             \
+    left = __builtin_uadd_overflow(q, (t), &q2); /* carries exactly when the probe fails (rem < t: go left) */          \
     bits = __builtin_amdgcn_alignbit(bits, q2, 31);                                                                    \
     q    = q > q2 ? q : q2;                                                                                            \
     hq   = hq < q2 ? hq : q2;
-    // levels 7, 6, 5: registers
-    REDUX_DEC_LEVEL(T.n128, 128u)
-    bool           r  = (int32_t)q2 < 0;
-    const uint32_t x6 = r ? T.n192 : T.n64, c5a = r ? T.n224 : T.n96, c5b = r ? T.n160 : T.n32;
-    REDUX_DEC_LEVEL(x6, 64u)
-    r                 = (int32_t)q2 < 0;
-    const uint32_t x5 = r ? c5a : c5b;
-    REDUX_DEC_LEVEL(x5, 32u)
+    bool left;
+    // levels 7, 6, 5: registers (full tree values: lowbit + increments)
+    REDUX_DEC_LEVEL(T.n128)
+    const uint32_t x6 = left ? T.n64 : T.n192, c5l = left ? T.n32 : T.n160, c5r = left ? T.n96 : T.n224;
+    REDUX_DEC_LEVEL(x6)
+    const uint32_t x5 = left ? c5l : c5r;
+    REDUX_DEC_LEVEL(x5)
     DEC_STAMP(2, bits)
     // round B: levels 4, 3 under the prefix i = bits << 5: nodes i+16; i+8, i+24 (three dwords)
     uint32_t       ib  = ((bits & 7u) << 12) | L;
     const uint32_t w16 = ld(ib + (16u << 7));
     const uint32_t w8 = ld(ib + (8u << 7)), w24 = ld(ib + (24u << 7));
-    REDUX_DEC_LEVEL(w16 & 0xFFFFu, 16u)
-    r                 = (int32_t)q2 < 0;
-    const uint32_t x3 = r ? w24 : w8;
-    REDUX_DEC_LEVEL(x3 & 0xFFFFu, 8u)
+    REDUX_DEC_LEVEL((w16 & 0xFFFFu) + 16u)
+    const uint32_t x3 = left ? w8 : w24;
+    REDUX_DEC_LEVEL((x3 & 0xFFFFu) + 8u)
     DEC_STAMP(3, bits)
     // round C: levels 2, 1, 0 under i = bits << 3.  The four dwords i/2 .. i/2+3 hold nodes
     // (i, i+1), (i+2, i+3), (i+4, i+5), (i+6, i+7): all seven candidates.
     ib                = ((bits & 31u) << 10) | L;
     const uint32_t d0 = ld(ib), d1 = ld(ib + 256u), d2 = ld(ib + 512u), d3 = ld(ib + 768u);
-    REDUX_DEC_LEVEL(d2 & 0xFFFFu, 4u) // node i+4
-    r                 = (int32_t)q2 < 0;
-    const uint32_t e1 = r ? d3 : d1; // level 1: node i+6 or i+2 (low halves)
-    const uint32_t e0 = r ? d2 : d0; // level 0 if level 1 goes left: node i+5 or i+1 (high halves)
-    REDUX_DEC_LEVEL(e1 & 0xFFFFu, 2u)
-    r                 = (int32_t)q2 < 0;
-    const uint32_t x0 = r ? e1 : e0; // ... if it goes right: node i+7 or i+3, the high half of level 1's dword
-    REDUX_DEC_LEVEL(x0 >> 16, 1u)
+    REDUX_DEC_LEVEL((d2 & 0xFFFFu) + 4u) // node i+4
+    const uint32_t e1 = left ? d1 : d3;  // level 1: node i+2 or i+6 (low halves)
+    const uint32_t e0 = left ? d0 : d2;  // level 0 if level 1 goes left: node i+1 or i+5 (high halves)
+    REDUX_DEC_LEVEL((e1 & 0xFFFFu) + 2u)
+    const uint32_t x0 = left ? e0 : e1;  // ... if it goes right: node i+3 or i+7, the high half of level 1's dword
+    REDUX_DEC_LEVEL((x0 >> 16) + 1u)
     DEC_STAMP(4, bits)
 #undef REDUX_DEC_LEVEL
     f.s  = bits & 0xFFu;
@@ -1127,7 +1124,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
     S.obuf  = 0;
     uint32_t stored = 0;
     uint32_t p      = 0;
-    DecTop   T      = {0, 0, 0, 0, 0, 0, 0};
+    DecTop   T      = dec_top_new();
 
 #define REDUX_DEC_READER                                                                                               \
     {                                                                                                                  \
