@@ -18,6 +18,8 @@ Extra objects on the JSON line:
                 PMC-measured HBM bytes per launch when profiles/traffic.json holds it.
   cpu_baseline  the CPU oracle (C restatement of the reference, kind "port") on a bounded
                 prefix of the same workload, on this box's host cores, rank 0 at N=1 only.
+  decode        (rank 0, after the timed steps, not part of `value`) one timed pass of the
+                decoder over the dense output, checked equal to the input on the device.
 """
 import argparse
 import json
@@ -60,7 +62,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=65536, help="blocks per GPU (default: the config's 65,536)")
     ap.add_argument("--workload", choices=["iid", "zipf"], default="iid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decode", action="store_true", help="also time the decode kernel (extra field decode_MBps)")
+    ap.add_argument("--decode", action="store_true", help="(default) also time the decode kernel after the timed encode steps")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode measurement / round-trip check")
     ap.add_argument("--cpu-sample-blocks", type=int, default=4096)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: usable cores)")
     args = ap.parse_args()
@@ -177,7 +180,7 @@ def main():
         },
     }
 
-    if args.decode:
+    if not args.no_decode:
         dec = rx.DeviceDecoder(PARAMS, BLOCK, nblocks, device=dev)
         offs_t = enc.offsets[: nblocks + 1]
         dense = enc.out[:out_bytes]
@@ -189,8 +192,10 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         assert d_sum.tolist() == [0, 0] and torch.equal(d_out, d_in), "decode(encode(x)) != x"
-        line["decode"] = {"ms": round(e0.elapsed_time(e1), 3), "MBps": round(n / (e0.elapsed_time(e1) * 1e-3) / 1e6, 1),
-                          "roundtrip_equal": True}
+        dms = e0.elapsed_time(e1)
+        line["decode"] = {"kernel": "k_decode_lock (u16 tree, one wave per 64 blocks)", "ms": round(dms, 3),
+                          "MBps": round(n / (dms * 1e-3) / 1e6, 1),
+                          "algorithmic_GBps": round(algo_bytes / (dms * 1e-3) / 1e9, 2), "roundtrip_equal": True}
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import cbind as ox
