@@ -332,6 +332,9 @@ struct ChunkQueue {
 #ifndef REDUX_MODEL_PRIO
 #define REDUX_MODEL_PRIO 3
 #endif
+#ifndef REDUX_MODEL_DEPTH
+#define REDUX_MODEL_DEPTH 1
+#endif
 template <bool UPD>
 __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, uint32_t lane, const uint4 cur,
                                             uint32_t p, uint32_t nfreeze)
@@ -340,7 +343,7 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
     auto sym = [&](int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; };
     // software pipeline: symbol i+1's LDS ops are in flight while symbol i's sums are formed
     // (depths 2 and 3 measured no faster: the wave is bound by its own issue rate, not by LDS)
-    constexpr int D = 1;
+    constexpr int D = REDUX_MODEL_DEPTH;
     Tree<true>::Nodes q[D + 1];
 #pragma unroll
     for (int d = 0; d < D; d++)

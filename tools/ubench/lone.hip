@@ -55,6 +55,9 @@ __global__ void __launch_bounds__(64) k(uint32_t *out, uint32_t seed, unsigned l
         if (T == 29) A(S256("v_dot2_u32_u16 %0, %4, %5, %0\n\t"));
         if (T == 30) A(S256("ds_write_b128 %1, v[40:43]\n\t") "s_waitcnt lgkmcnt(0)\n\t");
         if (T == 31) A(S256("v_min3_u32 %0, %0, %4, %5\n\t"));
+        if (T == 32) A(S128("v_add_u32 %0, %0, %4\n\ts_waitcnt lgkmcnt(0)\n\t"));   // per pair: does a satisfied s_waitcnt cost an issue slot?
+        if (T == 33) A(S128("v_add_u32 %0, %0, %4\n\ts_nop 0\n\t"));
+        if (T == 34) A(S128("v_add_u32 %0, %0, %4\n\ts_waitcnt vmcnt(0)\n\t"));
     }
     const unsigned long long c1 = clock64();
     out[blockIdx.x * 64 + threadIdx.x] = x + w + (uint32_t)d + (uint32_t)q;
@@ -77,6 +80,7 @@ int main()
         {"ds_read_b32 x256 then wait", 256, k<15>}, {"ds_read2st64_b32 x256 then wait", 256, k<16>}, {"ds_read_b64 x256 then wait", 256, k<25>},
         {"ds_read_b128 x256 then wait", 256, k<26>}, {"ds_add_u32 x256 then wait", 256, k<17>}, {"ds_add_rtn_u32 x256 then wait", 256, k<19>},
         {"ds_write_b32 x256 then wait", 256, k<18>}, {"ds_write_b128 x256 then wait", 256, k<30>}, {"ds_read_b32 pointer chase", 256, k<20>},
+        {"v_add + s_waitcnt lgkmcnt(0) (per PAIR)", 128, k<32>}, {"v_add + s_nop 0 (per PAIR)", 128, k<33>}, {"v_add + s_waitcnt vmcnt(0) (per PAIR)", 128, k<34>},
         {"s_add_u32 dep", 256, k<21>}, {"v_add + s_add interleaved (per instr)", 256, k<22>}, {"v_add + ds_read interleaved (per instr)", 256, k<23>},
     };
     for (auto &t : tests) {
