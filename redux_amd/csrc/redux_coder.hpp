@@ -386,6 +386,46 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
     }
 }
 
+// encode_symbol_fast without its careful path: the caller keeps a copy of the state, ORs the
+// returned ballot ("some lane needs more than one 32-bit append") over a run of symbols and,
+// if it is non-zero, restores the copy and redoes the run with encode_symbol.  A symbol that
+// needed the careful path leaves garbage in acc/nb, but `off` still advances by at most one
+// dword per symbol and never beyond what the redo writes, so every stray store is overwritten.
+template <bool FIXUP, bool CB32>
+__device__ __forceinline__ uint64_t encode_symbol_spec(EncState &S, uint32_t lo, uint32_t hi, uint32_t c, double rc,
+                                                       uint32_t sh_, uint8_t *wbase)
+{
+    const uint32_t sh = CB32 ? 0u : sh_;
+    const uint32_t R1 = (~(S.ihigh + S.low)) >> sh;
+    const double   Y  = __builtin_fma((double)R1, rc, rc);
+    const uint32_t nlow   = S.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
+    uint32_t       nihigh = 0u - (S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh));
+    asm volatile("" : "+v"(nihigh));
+    const uint32_t x    = ~(nlow ^ nihigh);
+    const uint32_t k    = x ? (uint32_t)__builtin_clz(x) : 32u;
+    const uint64_t sl   = (uint64_t)nlow << k;
+    const uint32_t topk = (uint32_t)(sl >> 32);
+    const uint32_t low2 = (uint32_t)sl;
+    const uint32_t ih2  = (uint32_t)((uint64_t)nihigh << k);
+    const uint32_t t    = (low2 & ih2) << 1;
+    const uint32_t j    = (uint32_t)__builtin_clz(~t);
+    S.low   = (low2 << j) & 0x7FFFFFFFu;
+    S.ihigh = (ih2 << j) & 0x7FFFFFFFu;
+    const uint32_t P  = S.pend;
+    const uint32_t Pz = k ? P : 0u;
+    S.pend            = P - Pz + j;
+    const uint32_t m  = k + Pz;
+    uint32_t run;
+    asm("v_bfm_b32 %0, %1, %2" : "=v"(run) : "v"(Pz), "v"(k - 1u));
+    S.acc = (S.acc << (m & 63u)) | (topk + run); // (the & 63 is what v_lshlrev_b64 does anyway: no instruction)
+    const uint32_t nb = S.nb + m;                // garbage for a lane that raised the flag; everything below stays bounded
+    if (nb >= 32)
+        *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u)));
+    S.off += (nb >> 3) & 4u;
+    S.nb = nb & 31u;
+    return __builtin_amdgcn_ballot_w64(m > 32);
+}
+
 // The EOF tail (codec.rs:91-99) + flush_bits (bitio/mod.rs:183-198).  `shifts` is what
 // encode_symbol returned for the EOF symbol.  Returns the block's stream length in bytes.
 __device__ __forceinline__ uint32_t encode_finish(EncState &S, uint32_t shifts, uint32_t cb, uint32_t off0,

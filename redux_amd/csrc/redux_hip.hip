@@ -402,6 +402,7 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
             for (int i = 0; i < 8; i++)
                 rn[i] = nb[i];
         }
+#ifdef REDUX_CODER_BRANCHY // the older form: a ballot branch inside every symbol
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
@@ -409,6 +410,28 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
             asm volatile("" : "+v"(hi)); // keeps ISel from turning (u64 >> 32) -> f64 into a 64-bit conversion (+1 v_add_f64)
             encode_symbol_fast<FIXUP, CB32>(S, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
         }
+#else
+        // Eight symbols straight-line; the rare symbol whose pending run needs more than one
+        // 32-bit append only raises a flag, and the half is then redone from the saved state
+        // with the general encode_symbol (no per-symbol branch, no merge of two state versions).
+        const EncState S0 = S;
+        uint64_t       bad = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
+            uint32_t       hi  = lh[i].y;
+            asm volatile("" : "+v"(hi)); // keeps ISel from turning (u64 >> 32) -> f64 into a 64-bit conversion (+1 v_add_f64)
+            bad |= encode_symbol_spec<FIXUP, CB32>(S, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
+        }
+        if (__builtin_expect(bad != 0, 0)) {
+            S = S0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
+                encode_symbol<FIXUP>(S, lh[i].x, lh[i].y, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, false, wdst, 0xFFFFFFFFu);
+            }
+        }
+#endif
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 8; i++)
