@@ -62,6 +62,7 @@ struct Tree {
     uint32_t  inc;  // +1 in this lane's slot of the dword
     uint32_t  sel;  // U16: v_perm selector picking this lane's halves of two dwords
     uint32_t  hsh;  // U16: bit position of this lane's slot (0 or 16)
+    uint32_t  nmask; // 0xFF << hsh
 
     // the eight node values of one symbol, possibly still in flight from LDS
     struct Nodes {
@@ -78,6 +79,8 @@ struct Tree {
         inc = (U16 && (lane >> 5)) ? 0x10000u : 1u;
         sel = (lane >> 5) ? 0x07060302u : 0x05040100u;
         hsh = (U16 && (lane >> 5)) ? 16u : 0u;
+        nmask = 0xFFu << hsh;
+        asm volatile("" : "+v"(nmask));
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             A[b] = (1u << (b + kShift)) | L;
@@ -120,7 +123,7 @@ struct Tree {
     __device__ __forceinline__ Nodes issue(uint32_t s, bool upd) const
     {
         const uint32_t ss  = s << kShift;
-        const uint32_t nsl = (s ^ 0xFFu) << hsh;
+        const uint32_t nsl = (s << hsh) ^ nmask; // (~s & 0xFF) << hsh with s already extracted: shift + xor
         const uint32_t iv  = upd ? inc : 0u;
         Nodes          n;
 #pragma unroll
@@ -419,9 +422,10 @@ __device__ __forceinline__ uint64_t encode_symbol_spec(EncState &S, uint32_t lo,
     asm("v_bfm_b32 %0, %1, %2" : "=v"(run) : "v"(Pz), "v"(k - 1u));
     S.acc = (S.acc << (m & 63u)) | (topk + run); // (the & 63 is what v_lshlrev_b64 does anyway: no instruction)
     const uint32_t nb = S.nb + m;                // garbage for a lane that raised the flag; everything below stays bounded
-    if (nb >= 32)
+    if (nb >= 32) { // one exec-masked region: shift, byte swap, store, advance
         *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u)));
-    S.off += (nb >> 3) & 4u;
+        S.off += 4;
+    }
     S.nb = nb & 31u;
     return __builtin_amdgcn_ballot_w64(m > 32);
 }
