@@ -423,8 +423,12 @@ __device__ __forceinline__ uint64_t encode_symbol_spec(EncState &S, uint32_t lo,
     S.acc = (S.acc << (m & 63u)) | (topk + run); // (the & 63 is what v_lshlrev_b64 does anyway: no instruction)
     const uint32_t nb = S.nb + m;                // garbage for a lane that raised the flag; everything below stays bounded
     if (nb >= 32) { // one exec-masked region: shift, byte swap, store, advance
+#ifndef REDUX_STORE_X4
         *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u)));
         S.off += 4;
+#else
+        emit_dword<false>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u))), wbase, 0);
+#endif
     }
     S.nb = nb & 31u;
     return __builtin_amdgcn_ballot_w64(m > 32);

@@ -6,8 +6,8 @@ for lib in "$@"; do
   cp $lib redux_amd/libredux_hip.so
   tag=$(basename $lib .so)
   echo "== $lib: $(timeout -k 10 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | grep -o 'kernel_ms[^}]*')"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/tab_$tag/f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/tab_$tag/w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/tab_$tag/f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/tab_$tag/w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   python3 tools/pmc_summary.py gpurun_out/tab_$tag k_encode | grep "SIZE"
 done
 cp /tmp/keep.so redux_amd/libredux_hip.so

@@ -55,6 +55,18 @@ __global__ void __launch_bounds__(64) k(uint32_t *out, uint32_t seed, unsigned l
         if (T == 29) A(S256("v_dot2_u32_u16 %0, %4, %5, %0\n\t"));
         if (T == 30) A(S256("ds_write_b128 %1, v[40:43]\n\t") "s_waitcnt lgkmcnt(0)\n\t");
         if (T == 31) A(S256("v_min3_u32 %0, %0, %4, %5\n\t"));
+        if (T == 35) A(S256("v_cvt_f64_i32 %2, %0\n\t"));
+        if (T == 36) A(S256("v_cvt_f64_u32 %2, %0\n\t"));
+        if (T == 37) A(S256("v_cvt_u32_f64 %0, %2\n\t"));
+        if (T == 38) A(S256("v_lshrrev_b64 %3, 1, %3\n\t"));
+        if (T == 39) A(S256("v_bfm_b32 %0, %0, %4\n\t"));
+        if (T == 40) A(S256("v_xnor_b32 %0, %0, %4\n\t"));
+        if (T == 41) A(S256("v_subrev_co_u32 %0, s[20:21], 1, %0\n\t"));
+        if (T == 42) A(S256("v_add_f64 %2, %2, %6\n\t"));
+        if (T == 43) A(S256("v_cvt_i32_f64 %0, %2\n\t"));
+        if (T == 44) A(S256("v_mul_u32_u24 %0, %0, %4\n\t"));
+        if (T == 45) A(S256("v_mad_u32_u24 %0, %0, %4, %5\n\t"));
+        if (T == 46) A(S256("v_lshl_add_u32 %0, %0, 3, %4\n\t"));
         if (T == 32) A(S128("v_add_u32 %0, %0, %4\n\ts_waitcnt lgkmcnt(0)\n\t"));   // per pair: does a satisfied s_waitcnt cost an issue slot?
         if (T == 33) A(S128("v_add_u32 %0, %0, %4\n\ts_nop 0\n\t"));
         if (T == 34) A(S128("v_add_u32 %0, %0, %4\n\ts_waitcnt vmcnt(0)\n\t"));
@@ -80,6 +92,9 @@ int main()
         {"ds_read_b32 x256 then wait", 256, k<15>}, {"ds_read2st64_b32 x256 then wait", 256, k<16>}, {"ds_read_b64 x256 then wait", 256, k<25>},
         {"ds_read_b128 x256 then wait", 256, k<26>}, {"ds_add_u32 x256 then wait", 256, k<17>}, {"ds_add_rtn_u32 x256 then wait", 256, k<19>},
         {"ds_write_b32 x256 then wait", 256, k<18>}, {"ds_write_b128 x256 then wait", 256, k<30>}, {"ds_read_b32 pointer chase", 256, k<20>},
+        {"v_cvt_f64_i32", 256, k<35>}, {"v_cvt_f64_u32", 256, k<36>}, {"v_cvt_u32_f64", 256, k<37>}, {"v_cvt_i32_f64", 256, k<43>}, {"v_lshrrev_b64", 256, k<38>},
+        {"v_bfm_b32", 256, k<39>}, {"v_xnor_b32", 256, k<40>}, {"v_subrev_co_u32 (sgpr carry)", 256, k<41>}, {"v_add_f64", 256, k<42>},
+        {"v_mul_u32_u24", 256, k<44>}, {"v_mad_u32_u24", 256, k<45>}, {"v_lshl_add_u32", 256, k<46>},
         {"v_add + s_waitcnt lgkmcnt(0) (per PAIR)", 128, k<32>}, {"v_add + s_nop 0 (per PAIR)", 128, k<33>}, {"v_add + s_waitcnt vmcnt(0) (per PAIR)", 128, k<34>},
         {"s_add_u32 dep", 256, k<21>}, {"v_add + s_add interleaved (per instr)", 256, k<22>}, {"v_add + ds_read interleaved (per instr)", 256, k<23>},
     };
