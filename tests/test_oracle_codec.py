@@ -148,3 +148,28 @@ def test_adversarial_inputs_c_equals_python(name, params, data):
     assert back == d
     sl, _ = ox.compress(d, params, ox.LINEAR)
     assert sl == s
+
+
+GENERAL_PARAMS = [(4, 10, 16), (12, 14, 16), (8, 24, 40), (1, 3, 5), (16, 18, 20), (2, 30, 34), (8, 30, 33),
+                  (12, 20, 44), (7, 9, 55), (3, 31, 33)]
+
+
+@pytest.mark.parametrize("params", GENERAL_PARAMS)
+def test_general_parameters_c_equals_python(params):
+    """The two restatements agree outside the CLI's (8, 30, 32) as well: other symbol widths,
+    code_bits > 32, linear == tree, and what decompress returns when symbol_bits does not divide
+    the input (the trailing bits are dropped, lib.rs:113-120).  These are the streams the GPU's
+    general-parameter path (redux_any.hpp) is compared with."""
+    rnd = random.Random(sum(params))
+    for n, hi in ((0, 256), (1, 256), (700, 256), (1500, 3)):
+        data = bytes(rnd.randrange(hi) for _ in range(n))
+        s, c = ox.compress(data, params, ox.TREE)
+        s2, c2 = rr.compress(data, rr.AdaptiveTreeModel(rr.Parameters(*params)))
+        assert s == s2 and c == c2, (params, n)
+        sl, cl = ox.compress(data, params, ox.LINEAR)
+        assert sl == s and cl == c
+        d, dc = ox.decompress(s, params, ox.TREE, cap=len(data) + 8)
+        d2, dc2 = rr.decompress(s, rr.AdaptiveTreeModel(rr.Parameters(*params)))
+        assert d == d2 and dc == dc2
+        whole = (len(data) * 8 // params[0]) * params[0] // 8  # bytes made only of whole symbols
+        assert d == data[: len(d)] and len(d) >= whole - 1 and dc[0] == len(s)
