@@ -612,7 +612,7 @@ struct DecArgs {
     uint32_t        block_size;
     uint32_t        nfreeze;
     uint32_t        code_bits;
-    uint32_t        aligned4;   // out and block_size are 4-byte multiples
+    uint32_t        aligned4;   // 1: out and block_size are 4-byte multiples; 2: 16-byte multiples
     uint64_t       *in_used;    // optional: bytes of each stream the reader fetched (ByteCount, bitio/mod.rs:71)
 };
 
@@ -1094,6 +1094,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
     const rc_ptr   rcp         = (rc_ptr)a.rc;
     const uint32_t nfreeze     = a.nfreeze;
     const bool     aligned4    = a.aligned4 != 0;
+    const bool     aligned16   = a.aligned4 == 2;
 
     // Bit reader (bitio/mod.rs:78-120).  The stream is read as aligned dwords from a per-lane base.
     // A lock-step wave waits for the SLOWEST of its 64 lanes on every vector-memory wait, and
@@ -1161,7 +1162,9 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
     S.sbits = (int32_t)S.dflag < 0 ? 0u : stream_bits;
     S.n_out = 0;
     S.obuf  = 0;
-    uint32_t stored = 0;
+    uint32_t stored = 0; // bytes [0, stored) of the block are in memory
+    uint32_t staged = 0; // bytes [stored, staged) are whole dwords waiting in oq (newest in .w)
+    uint4    oq     = make_uint4(0, 0, 0, 0);
     uint32_t p      = 0;
     DecTop   T      = dec_top_new();
 
@@ -1182,11 +1185,26 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
 #define REDUX_DEC_RETIRE                                                                                               \
     if (pend)                                                                                                          \
         ring_write(pend_chunk, ldq.x, ldq.y, ldq.z, ldq.w);
+    // Output: a finished group's dword is staged; 16-byte aligned blocks get one 16-byte store per
+    // four groups (p is wave-uniform, so that is a scalar branch).  A 4-byte store every four steps
+    // per lane is what the L2's background cleaning of resident dirty lines turns into ten times
+    // the output in fabric writes (WRITE_SIZE 43e6 KiB for 4 GiB).
 #define REDUX_DEC_STORE                                                                                                \
-    if (aligned4 && (int32_t)S.dflag >= 0 && p > stored) { /* a live lane has emitted p symbols */                  \
+    if (aligned16) {                                                                                                   \
+        if ((int32_t)S.dflag >= 0 && p > staged) { /* a live lane has emitted p symbols */                             \
+            oq     = make_uint4(oq.y, oq.z, oq.w, S.obuf);                                                             \
+            S.obuf = 0;                                                                                                \
+            staged = p;                                                                                                \
+            if ((p & 15u) == 0) {                                                                                      \
+                *reinterpret_cast<uint4 *>(dst + (p - 16)) = oq;                                                       \
+                stored = p;                                                                                            \
+            }                                                                                                          \
+        }                                                                                                              \
+    } else if (aligned4 && (int32_t)S.dflag >= 0 && p > stored) {                                                      \
         *reinterpret_cast<uint32_t *>(dst + (p - 4)) = S.obuf;                                                         \
         S.obuf = 0;                                                                                                    \
         stored = p;                                                                                                    \
+        staged = p;                                                                                                    \
     }
 #define REDUX_DEC_REQUEST                                                                                              \
     {                                                                                                                  \
@@ -1347,9 +1365,18 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
 #undef REDUX_DEC_STORE
 #undef REDUX_DEC_REQUEST
     if (live) {
-        if (aligned4)
-            for (uint32_t i = stored; i < S.n_out; i++)
+        if (aligned4) {
+            // the 0..3 staged dwords (oldest first: the last k components of oq), then the partial one
+            const uint32_t k = (staged - stored) >> 2;
+            const uint32_t comp[4] = {oq.x, oq.y, oq.z, oq.w};
+            for (uint32_t j = 0; j < k; j++) {
+                const uint32_t idx = 4 - k + j;
+                const uint32_t w   = idx == 0 ? comp[0] : idx == 1 ? comp[1] : idx == 2 ? comp[2] : comp[3];
+                *reinterpret_cast<uint32_t *>(dst + stored + 4 * j) = w;
+            }
+            for (uint32_t i = staged; i < S.n_out; i++)
                 dst[i] = (uint8_t)(S.obuf >> (8 * (i & 3)));
+        }
         a.out_sizes[blk] = S.n_out;
         a.status[blk]    = S.st;
         if (a.in_used) { // the reader fetches whole bytes, and never past the end of the stream
@@ -2074,6 +2101,8 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     a.nfreeze    = g.nfreeze;
     a.code_bits  = p->code_bits;
     a.aligned4   = ((((uintptr_t)d_out) & 3) == 0 && (block_size & 3) == 0) ? 1 : 0;
+    if (a.aligned4 && (((uintptr_t)d_out) & 15) == 0 && (block_size & 15) == 0)
+        a.aligned4 = 2; // 16-byte aligned blocks: the lock-step decoder stages four dwords per store
     a.in_used    = (uint64_t *)d_in_used;
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
     const char *force = getenv("REDUX_DECODE_KERNEL"); // "generic" pins k_decode (A/B timing only)
