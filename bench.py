@@ -57,8 +57,8 @@ def host_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=10)  # the chip's clocks settle only after ~0.2 s of load
     ap.add_argument("--blocks", type=int, default=65536, help="blocks per GPU (default: the config's 65,536)")
     ap.add_argument("--workload", choices=["iid", "zipf"], default="iid")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -3,8 +3,8 @@
 # Usage: tools/round_end.sh <tag>   -> gpurun_out/final_<tag>/...
 TAG=${1:-x}; OUT=gpurun_out/final_$TAG; mkdir -p $OUT
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/tests_gpu.log 2>&1; tail -2 $OUT/tests_gpu.log
-timeout -k 10 300 python bench.py --steps 5 --warmup 1 --decode > $OUT/bench_iid.log 2>&1 && tail -1 $OUT/bench_iid.log
-timeout -k 10 300 python bench.py --steps 5 --warmup 1 --decode --workload zipf --no-cpu-baseline > $OUT/bench_zipf.log 2>&1 && tail -1 $OUT/bench_zipf.log
+timeout -k 10 300 python bench.py --steps 10 --warmup 10 > $OUT/bench_iid.log 2>&1 && tail -1 $OUT/bench_iid.log
+timeout -k 10 300 python bench.py --steps 10 --warmup 10 --workload zipf --no-cpu-baseline > $OUT/bench_zipf.log 2>&1 && tail -1 $OUT/bench_zipf.log
 timeout -k 10 300 python tools/measure_extra.py > $OUT/extra.log 2>&1 && tail -1 $OUT/extra.log
 timeout -k 10 600 bash tools/prof.sh $TAG > $OUT/prof.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/prof_$TAG > $OUT/prof_summary.txt 2>&1
