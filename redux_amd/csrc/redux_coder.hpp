@@ -229,14 +229,17 @@ __device__ __forceinline__ void enc_init(EncState &S, uint32_t off0) // codec.rs
 // write at 32-byte granularity), at 6 % more kernel time; not the default because the kernel
 // is VALU-bound and the partial writes merge in the Infinity Cache.
 // `off` is always the byte offset of the NEXT dword; slots start 16-byte aligned.
-template <bool CHECKED>
+// ST: distance between a lane's consecutive dwords: 4 in a linear slot; 256 in a ROW-major group
+// area, where row r holds dword r of the group's 64 lanes (see Geometry in redux_hip.hip).
+template <bool CHECKED, int ST = 4>
 __device__ __forceinline__ void emit_dword(EncState &S, uint32_t w, uint8_t *wbase, uint32_t limit)
 {
 #ifndef REDUX_STORE_X4 // default: one 4-byte store per completed group
-    if (!CHECKED || S.off + 4 <= limit)
+    if (!CHECKED || S.off + ST <= limit)
         *reinterpret_cast<uint32_t *>(wbase + S.off) = w;
-    S.off += 4;
+    S.off += ST;
 #else
+    static_assert(ST == 4, "staged 16-byte stores need linear slots");
     S.q = make_uint4(S.q.y, S.q.z, S.q.w, w); // shift in place: the quad is stored as it stands
     if ((S.off & 12u) == 12u && (!CHECKED || S.off + 4 <= limit))
         *reinterpret_cast<uint4 *>(wbase + (S.off - 12u)) = S.q;
@@ -259,20 +262,22 @@ __device__ __forceinline__ void flush_staged(EncState &S, uint8_t *wbase, uint32
         *reinterpret_cast<uint32_t *>(wbase + (S.off - 4u)) = S.q.w;
 }
 
+template <int ST = 4>
 __device__ __forceinline__ void put_bits(EncState &S, uint32_t val, uint32_t m, uint8_t *wbase, uint32_t limit)
 {
     S.acc = (S.acc << m) | val; // m <= 32
     const uint32_t nb = S.nb + m;
     if (nb >= 32)
-        emit_dword<true>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32))), wbase, limit);
+        emit_dword<true, ST>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32))), wbase, limit);
     S.nb = nb & 31u;
 }
 
+template <int ST = 4>
 __device__ __forceinline__ void put_run(EncState &S, uint32_t bit, uint32_t n, uint8_t *wbase, uint32_t limit)
 {
     while (n > 0) {
         const uint32_t m = n < 32 ? n : 32;
-        put_bits(S, bit ? (0xFFFFFFFFu >> (32 - m)) : 0u, m, wbase, limit);
+        put_bits<ST>(S, bit ? (0xFFFFFFFFu >> (32 - m)) : 0u, m, wbase, limit);
         n -= m;
     }
 }
@@ -289,7 +294,7 @@ __device__ __forceinline__ void put_run(EncState &S, uint32_t bit, uint32_t n, u
 //     b, !b x pending, next k-1 bits of low      (b = top bit of low)
 // and "b followed by P copies of !b" is the number (2^P - 1) + b, so the whole string is
 //     top_k_bits(low) + ((2^P - 1) << (k-1))     in k + P bits.
-template <bool FIXUP>
+template <bool FIXUP, int ST = 4>
 __device__ __forceinline__ uint32_t encode_symbol(EncState &S, uint32_t lo, uint32_t hi, uint32_t c, double rc,
                                                   uint32_t sh, bool is_eof, uint8_t *wbase, uint32_t limit)
 {
@@ -314,12 +319,12 @@ __device__ __forceinline__ uint32_t encode_symbol(EncState &S, uint32_t lo, uint
     const uint32_t Pz = k ? P : 0u; // pending bits flushed by this symbol
     S.pend            = P - Pz + j;
     if (k + Pz <= 32) {
-        put_bits(S, topk + (((1u << Pz) - 1u) << ((k - 1u) & 31u)), k + Pz, wbase, limit);
+        put_bits<ST>(S, topk + (((1u << Pz) - 1u) << ((k - 1u) & 31u)), k + Pz, wbase, limit);
     } else { // long pending run: rare, bit-serial in spirit
         const uint32_t b = topk >> (k - 1);
-        put_bits(S, b, 1, wbase, limit);
-        put_run(S, b ^ 1u, P, wbase, limit);
-        put_bits(S, topk & ((1u << (k - 1)) - 1u), k - 1, wbase, limit);
+        put_bits<ST>(S, b, 1, wbase, limit);
+        put_run<ST>(S, b ^ 1u, P, wbase, limit);
+        put_bits<ST>(S, topk & ((1u << (k - 1)) - 1u), k - 1, wbase, limit);
     }
     return k + j;
 }
@@ -394,7 +399,7 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
 // if it is non-zero, restores the copy and redoes the run with encode_symbol.  A symbol that
 // needed the careful path leaves garbage in acc/nb, but `off` still advances by at most one
 // dword per symbol and never beyond what the redo writes, so every stray store is overwritten.
-template <bool FIXUP, bool CB32>
+template <bool FIXUP, bool CB32, int ST = 4>
 __device__ __forceinline__ uint64_t encode_symbol_spec(EncState &S, uint32_t lo, uint32_t hi, uint32_t c, double rc,
                                                        uint32_t sh_, uint8_t *wbase)
 {
@@ -425,9 +430,9 @@ __device__ __forceinline__ uint64_t encode_symbol_spec(EncState &S, uint32_t lo,
     if (nb >= 32) { // one exec-masked region: shift, byte swap, store, advance
 #ifndef REDUX_STORE_X4
         *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u)));
-        S.off += 4;
+        S.off += ST;
 #else
-        emit_dword<false>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u))), wbase, 0);
+        emit_dword<false, ST>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u))), wbase, 0);
 #endif
     }
     S.nb = nb & 31u;
@@ -436,28 +441,30 @@ __device__ __forceinline__ uint64_t encode_symbol_spec(EncState &S, uint32_t lo,
 
 // The EOF tail (codec.rs:91-99) + flush_bits (bitio/mod.rs:183-198).  `shifts` is what
 // encode_symbol returned for the EOF symbol.  Returns the block's stream length in bytes.
+template <int ST = 4>
 __device__ __forceinline__ uint32_t encode_finish(EncState &S, uint32_t shifts, uint32_t cb, uint32_t off0,
                                                   uint8_t *wbase, uint32_t limit)
 {
     if (shifts < cb) {
         const uint32_t extra = cb - shifts;
         const uint32_t b     = S.low >> 31;
-        put_bits(S, b, 1, wbase, limit);
-        put_run(S, b ^ 1u, S.pend, wbase, limit);
+        put_bits<ST>(S, b, 1, wbase, limit);
+        put_run<ST>(S, b ^ 1u, S.pend, wbase, limit);
         S.pend = 0;
         const uint32_t rest = extra - 1;
         if (rest > 0)
-            put_bits(S, (S.low << 1) >> (32 - rest), rest, wbase, limit);
+            put_bits<ST>(S, (S.low << 1) >> (32 - rest), rest, wbase, limit);
     }
     flush_staged(S, wbase, limit);
     const uint32_t nbytes = (S.nb + 7) >> 3;
     const uint64_t tail   = S.nb ? (S.acc << (64 - S.nb)) : 0; // left-align, zero padding
-    for (uint32_t i = 0; i < nbytes; i++)
-        if (S.off + i < limit)
+    for (uint32_t i = 0; i < nbytes; i++) // nbytes <= 4: inside one dword in either layout
+        if (S.off + (ST == 4 ? i : (uint32_t)ST - 1u) < limit)
             wbase[S.off + i] = (uint8_t)(tail >> (56 - 8 * i));
+    const uint32_t size = (S.off - off0) / ST * 4 + nbytes; // dropped stores are still counted
     S.off += nbytes;
     S.nb = 0;
-    return S.off - off0;
+    return size;
 }
 
 } // namespace redux

@@ -332,6 +332,10 @@ struct ChunkQueue {
 #ifndef REDUX_MODEL_PRIO
 #define REDUX_MODEL_PRIO 3
 #endif
+#ifndef REDUX_ROWS // 1: the pair kernel writes ROW-major group areas (row r = dword r of the 64 lanes), k_compact_rows gathers them
+#define REDUX_ROWS 0
+#endif
+constexpr int kPairStride = REDUX_ROWS ? 256 : 4;
 #ifndef REDUX_MODEL_DEPTH
 #define REDUX_MODEL_DEPTH 1
 #endif
@@ -423,14 +427,14 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
             // keeps ISel from turning (u64 >> 32) -> f64 into a 64-bit conversion (+1 v_add_f64); converting
             // as signed avoids that too, but v_cvt_f64_i32 measured 9 % slower for the whole kernel
             asm volatile("" : "+v"(hi));
-            bad |= encode_symbol_spec<FIXUP, CB32>(S, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
+            bad |= encode_symbol_spec<FIXUP, CB32, kPairStride>(S, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
         }
         if (__builtin_expect(bad != 0, 0)) {
             S = S0;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
-                encode_symbol<FIXUP>(S, lh[i].x, lh[i].y, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, false, wdst, 0xFFFFFFFFu);
+                encode_symbol<FIXUP, kPairStride>(S, lh[i].x, lh[i].y, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, false, wdst, 0xFFFFFFFFu);
             }
         }
 #endif
@@ -454,7 +458,7 @@ __device__ __forceinline__ void coder_chunk_checked(EncState &S, const uint2 *ri
         const uint2    lh  = ring[i * 64 + lane];
         const uint32_t q   = p + i;
         const uint32_t nup = q < nfreeze ? q : nfreeze;
-        encode_symbol<FIXUP>(S, lh.x, lh.y, 257u + nup, rc[nup], sh, false, wdst, limit);
+        encode_symbol<FIXUP, kPairStride>(S, lh.x, lh.y, 257u + nup, rc[nup], sh, false, wdst, limit);
     }
 }
 
@@ -484,16 +488,25 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
     }
     const uint8_t *wsrc  = a.in + blk0 * a.block_size;
     const uint32_t soff  = live ? lane * a.block_size : 0u;
+#if REDUX_ROWS
+    // row-major group area: dword r of lane l at wdst + 256 r + 4 l (dead lanes own a column too).
+    // The areas are an ODD number of 128-byte lines apart: all groups write row r at about the
+    // same time, and an even stride folds those lines onto a fraction of the L2 sets.
+    uint8_t       *wdst  = a.slots + (uint64_t)blockIdx.x * (64 * a.slot_bytes + 128);
+    const uint32_t off0  = lane * 4u;
+    const uint32_t limit = off0 + (a.slot_cap / 4u) * 256u;
+#else
     uint8_t       *wdst  = a.slots + blk0 * a.slot_bytes;
     const uint32_t off0  = live ? lane * (uint32_t)a.slot_bytes : (uint32_t)(a.nblocks - blk0) * (uint32_t)a.slot_bytes;
     const uint32_t limit = off0 + a.slot_cap;
+#endif
 
     const uint32_t minlen  = __builtin_amdgcn_readfirstlane(wave_min(live ? len : 0xFFFFFFFFu));
     const uint32_t maxlen  = __builtin_amdgcn_readfirstlane(wave_max(live ? len : 0u));
     const uint32_t sh      = 32 - a.code_bits;
     const uint32_t nfreeze = a.nfreeze;
     const rc_ptr   rc      = (rc_ptr)a.rc;
-    constexpr uint32_t kChunkBudget = 16 * 4 + 32;
+    constexpr uint32_t kChunkBudget = (16 * 4 + 32) * (kPairStride / 4);
 
     // both waves derive the same chunk schedule from wave-uniform values
     uint32_t main_end = 0;
@@ -588,10 +601,10 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
         if (live && p < len) {
             uint32_t lo, hi;
             T.template get_frequency<true>(wsrc[soff + p], nup, p < nfreeze && p + 1 != len, lo, hi);
-            encode_symbol<FIXUP>(S, lo, hi, c, r, sh, false, wdst, limit);
+            encode_symbol<FIXUP, kPairStride>(S, lo, hi, c, r, sh, false, wdst, limit);
         } else if (live && p == len) {
-            const uint32_t shifts = encode_symbol<FIXUP>(S, c - 1, c, c, r, sh, true, wdst, limit);
-            const uint32_t size   = encode_finish(S, shifts, a.code_bits, off0, wdst, limit);
+            const uint32_t shifts = encode_symbol<FIXUP, kPairStride>(S, c - 1, c, c, r, sh, true, wdst, limit);
+            const uint32_t size   = encode_finish<kPairStride>(S, shifts, a.code_bits, off0, wdst, limit);
             a.sizes[blk]  = size;
             a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
         }
@@ -1518,12 +1531,14 @@ struct CompactArgs {
     int32_t        *status;
     int32_t        *summary;
     uint64_t        nblocks;
+    const uint32_t *mode;     // 0: linear slots (k_compact), != 0: row-major group areas (k_compact_rows)
+    uint32_t        cap_rows; // rows of a group area
 };
 
 __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
 {
     const uint64_t b = blockIdx.x;
-    if (b >= a.nblocks)
+    if (b >= a.nblocks || *a.mode != 0)
         return;
     const uint64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
     const uint32_t tid = threadIdx.x;
@@ -1571,6 +1586,116 @@ __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
     const uint32_t done = head + (nchunks << 4);
     if (tid < n - done)
         dst[done + tid] = src[done + tid];
+}
+
+// Row-major group areas (REDUX_ROWS): row r of group g holds dword r of its 64 streams
+// (slots + g * 64 * slot_bytes + 256 r + 4 l).  One workgroup gathers a tile of 64 rows: the
+// rows are read whole (coalesced) into LDS, then every stream's 64 dwords of the tile leave as
+// one 256-byte run of ALIGNED dwords of the dense output: output dword j of a stream that starts
+// at byte offset sh (0..3) inside its first aligned dword is the byte-funnel of source dwords
+// j-1 and j.  Only a stream's first and last output dword can be partial: those go bytewise.
+constexpr uint32_t kTileRows = 64;
+__global__ void __launch_bounds__(256) k_compact_rows(CompactArgs a)
+{
+    if (*a.mode == 0)
+        return;
+    __shared__ uint32_t tile[(kTileRows + 1) * 65]; // +1 leading row (source dword j-1); pitch 65: conflict-free column reads
+    __shared__ uint64_t s_dst[64];                  // aligned dword that holds each stream's first byte (0: skip the stream)
+    __shared__ uint32_t s_n[64], s_sh[64];
+    __shared__ uint32_t s_maxj;
+    const uint32_t tiles = (a.cap_rows + kTileRows - 1) / kTileRows + 1;
+    const uint64_t g     = blockIdx.x / tiles;
+    const uint32_t r0    = (blockIdx.x % tiles) * kTileRows;
+    const uint32_t tid   = threadIdx.x;
+    if (tid == 0)
+        s_maxj = 0;
+    __syncthreads();
+    if (tid < 64) { // where does each stream go, and how many output dwords does the longest one need?
+        const uint64_t b = g * 64 + tid;
+        uint64_t       d = 0;
+        uint32_t       n = 0, sh = 0;
+        if (b < a.nblocks) {
+            const uint64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
+            if (o1 <= a.out_cap) {
+                n  = (uint32_t)(o1 - o0);
+                sh = (uint32_t)((uintptr_t)(a.out + o0) & 3);
+                d  = (uint64_t)(uintptr_t)(a.out + o0) - sh;
+                atomicMax(&s_maxj, (sh + n + 3) >> 2);
+            } else if (r0 == 0) { // the dense buffer is too small for this block: report, never write
+                if (a.status[b] == REDUX_OK)
+                    a.status[b] = REDUX_OUTPUT_TOO_SMALL;
+                if (a.summary) {
+                    atomicCAS(&a.summary[0], REDUX_OK, REDUX_OUTPUT_TOO_SMALL);
+                    atomicAdd(&a.summary[1], 1);
+                }
+            }
+        }
+        s_dst[tid] = d;
+        s_n[tid]   = n;
+        s_sh[tid]  = sh;
+    }
+    __syncthreads();
+    if (r0 >= s_maxj)
+        return;
+    const uint4 *area = reinterpret_cast<const uint4 *>(a.slots + g * (64 * a.slot_bytes + 128));
+    // tile row i (0..64) = source row r0 - 1 + i; a row is 16 uint4.  All loads first, then the LDS writes.
+    uint4 v[4], lead = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t e = tid + 256 * q, r = r0 + (e >> 4);
+        v[q] = r < a.cap_rows ? area[(uint64_t)r * 16 + (e & 15)] : make_uint4(0, 0, 0, 0);
+    }
+    if (tid < 16 && r0 > 0)
+        lead = area[(uint64_t)(r0 - 1) * 16 + tid];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t e = tid + 256 * q;
+        uint32_t      *w = &tile[((e >> 4) + 1) * 65 + (e & 15) * 4];
+        w[0] = v[q].x; w[1] = v[q].y; w[2] = v[q].z; w[3] = v[q].w;
+    }
+    if (tid < 16) {
+        uint32_t *w = &tile[tid * 4];
+        w[0] = lead.x; w[1] = lead.y; w[2] = lead.z; w[3] = lead.w;
+    }
+    __syncthreads();
+    // thread -> (stream, four consecutive output dwords): one 16-byte store where the whole quad is inside the stream
+    const uint32_t wave = tid >> 6, t = tid & 63;
+#pragma unroll 2
+    for (uint32_t it = 0; it < 4; it++) {
+        const uint32_t l  = wave * 16 + it * 4 + (t >> 4);
+        const uint32_t jq = (t & 15) * 4; // tile-relative first output dword
+        const uint64_t d  = s_dst[l];
+        const uint32_t n = s_n[l], sh = s_sh[l];
+        const uint32_t j0 = r0 + jq;
+        if (d == 0 || j0 >= ((sh + n + 3) >> 2))
+            continue;
+        uint32_t src[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            src[c] = tile[(jq + c) * 65 + l]; // source dwords j0-1 .. j0+3
+        uint32_t w[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            w[c] = sh ? __builtin_amdgcn_alignbyte(src[c + 1], src[c], 4 - sh) : src[c + 1];
+        uint8_t      *A     = reinterpret_cast<uint8_t *>((uintptr_t)d) + 4 * (uint64_t)j0;
+        const int64_t first = (int64_t)4 * j0 - sh; // stream index of the quad's byte 0
+        if (first >= 0 && first + 16 <= (int64_t)n) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+            *reinterpret_cast<u32x4 *>(A) = u32x4{w[0], w[1], w[2], w[3]};
+        } else { // a stream's head or tail: dwords where whole, bytes where not
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int64_t f = first + 4 * c;
+                if (f >= 0 && f + 4 <= (int64_t)n) {
+                    *reinterpret_cast<uint32_t *>(A + 4 * c) = w[c];
+                } else {
+                    for (int i = 0; i < 4; i++)
+                        if (f + i >= 0 && f + i < (int64_t)n)
+                            A[4 * c + i] = (uint8_t)(w[c] >> (8 * i));
+                }
+            }
+        }
+    }
 }
 
 // ======================================================================================
@@ -1719,7 +1844,7 @@ struct Geometry {
     bool     any;        // general-parameter path (redux_any.hpp): symbol_bits != 8 or code_bits > 32
     uint64_t tree_bytes; // any: per-block tree in the workspace
     // workspace layout (encode)
-    uint64_t off_rc, off_sizes, off_slots, off_trees, total;
+    uint64_t off_rc, off_sizes, off_mode, off_slots, off_trees, total;
 };
 
 static int check_params(const redux_params *p)
@@ -1790,8 +1915,10 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     }
     g.off_rc    = 0;
     g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
-    g.off_slots = align_up(g.off_sizes + g.nblocks * 4, 256);
-    g.off_trees = align_up(g.off_slots + (g.nblocks + 1) * g.slot_bytes, 256); // +1: spare slot for dead lanes
+    g.off_mode  = align_up(g.off_sizes + g.nblocks * 4, 256); // one word: 0 linear slots, != 0 row-major group areas
+    g.off_slots = g.off_mode + 256;
+    // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode
+    g.off_trees = align_up(g.off_slots + ((g.nblocks + 63) / 64 * 64 + 1) * g.slot_bytes + (g.nblocks + 63) / 64 * 128, 256);
     g.total     = g.off_trees + g.nblocks * g.tree_bytes;
     return g;
 }
@@ -1868,6 +1995,7 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     hipStream_t s  = (hipStream_t)stream;
     uint8_t    *ws = (uint8_t *)d_workspace;
 
+    HIP_TRY(hipMemsetAsync(ws + g.off_mode, 0, 4, s)); // linear slots unless the pair kernel runs (below)
     if (g.any) {
         AnyEncArgs aa;
         aa.in         = (const uint8_t *)d_in;
@@ -1911,6 +2039,10 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     const char *force = getenv("REDUX_ENCODE_KERNEL");
     const bool  pair  = g.u16 && a.aligned16 && a.lanes == 64 && !(force && !strcmp(force, "single"));
     // (a u16 tree means blocks of <= 65536 symbols, so count < 2^17: the pair kernel never needs FIXUP)
+#if REDUX_ROWS
+    if (pair && !g.fixup)
+        HIP_TRY(hipMemsetAsync(ws + g.off_mode, 1, 4, s));
+#endif
     if (pair && !g.fixup && p->code_bits == 32)
         k_encode_pair<false, true><<<grid, 128, 0, s>>>(a);
     else if (pair && !g.fixup)
@@ -1957,7 +2089,15 @@ int redux_compact_slots_dev(const redux_params *p, uint64_t in_len, uint32_t blo
     ca.status     = (int32_t *)d_block_status;
     ca.summary    = (int32_t *)d_summary;
     ca.nblocks    = g.nblocks;
+    ca.mode       = (const uint32_t *)(ws + g.off_mode);
+    ca.cap_rows   = (uint32_t)(g.slot_bytes / 4);
     k_compact<<<(uint32_t)g.nblocks, 256, 0, s>>>(ca);
+#if REDUX_ROWS // the mode word decides on the device which of the two does the work
+    if (!g.any && g.u16) {
+        const uint32_t tiles = (ca.cap_rows + kTileRows - 1) / kTileRows + 1;
+        k_compact_rows<<<(uint32_t)((g.nblocks + 63) / 64) * tiles, 256, 0, s>>>(ca);
+    }
+#endif
     HIP_TRY(hipGetLastError());
     return REDUX_OK;
 }
