@@ -587,7 +587,11 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
     if (lane == 0) {
         lds64p st = (lds64p)(uintptr_t)(wave * 32);
         unsigned long long *dstp = reinterpret_cast<unsigned long long *>(a.slots + a.nblocks * a.slot_bytes) + (blockIdx.x * 2 + wave) * 4;
-        dstp[0] = st[1]; dstp[1] = st[2]; dstp[2] = st[3]; dstp[3] = wave;
+        uint32_t hwid, xcc; // where this wave ran: (xcc, se, sh, cu, simd) -- the pair needs one model and one coder wave per SIMD
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dstp[0] = st[1]; dstp[1] = st[2]; dstp[2] = st[3];
+        dstp[3] = wave | ((unsigned long long)(hwid & 0xFFFFu) << 8) | ((unsigned long long)(xcc & 0xFu) << 24);
     }
 #endif
     if (wave == 0)
