@@ -52,6 +52,7 @@ struct EncArgs {
     uint32_t       code_bits;
     uint32_t       aligned16; // in and block_size are 16-byte multiples
     uint32_t       lanes;     // live lanes per wave: 64, or 1 when 64 slots overflow 32-bit offsets
+    uint32_t      *claims;    // kClaimWords words, zero at launch: k_encode_pair's per-CU role book
 };
 
 __device__ __forceinline__ uint32_t wave_min(uint32_t v)
@@ -462,13 +463,26 @@ __device__ __forceinline__ void coder_chunk_checked(EncState &S, const uint2 *ri
     }
 }
 
+// The pair kernel needs every SIMD to hold exactly ONE model wave and ONE coder wave.  Where the
+// two waves of a 128-thread workgroup land is up to the dispatcher: launched on an idle chip it
+// alternates them perfectly, launched right after another kernel it puts two first-waves on
+// some SIMDs (profiles/r01_final/placement_census.txt) -- two model waves at half speed each,
+// which the whole lock-step kernel then waits for (0.5-3 ms of 13).  So the roles are not tied
+// to the wave index: they are booked per CU at run time (REDUX_CLAIMS, below).
+// (Tried instead: whole-CU workgroups of eight waves = four pairs, waves w and w+4 sharing a
+// SIMD.  Placement is then perfect by construction, but the eight-wave s_barrier couples the
+// four pairs and the kernel takes 14.05 ms against 12.8 ms.)
+#ifndef REDUX_CLAIMS
+#define REDUX_CLAIMS 1
+#endif
+constexpr uint32_t kClaimWords = 2048; // (xcc:3, se:3, sh:1, cu:4) -> one word per CU
+constexpr uint32_t kPairDwords = Tree<true>::kDwords + kRingBytes / 4;
+
 template <bool FIXUP, bool CB32>
 __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
 {
-    __shared__ uint32_t lds[Tree<true>::kDwords + kRingBytes / 4];
-    // wave 0 = model, wave 1 = coder.  A census with this launch shape (tools/ubench/census.hip)
-    // shows every SIMD holding exactly one wave 0 and one wave 1 of different workgroups.
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ uint32_t lds[kPairDwords];
+    const uint32_t w8   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // first or second wave of the workgroup
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t blk0 = (uint64_t)blockIdx.x * a.lanes;
     const uint64_t blk  = blk0 + lane;
@@ -476,10 +490,50 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
 
     for (uint32_t i = threadIdx.x; i < Tree<true>::kDwords / 4; i += 128)
         reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    uint32_t role = w8;
+    uint2   *ring = reinterpret_cast<uint2 *>(lds + Tree<true>::kDwords);
+#if REDUX_CLAIMS
+    // claims[cu] counts the model waves (bits 4s..4s+3) and coder waves (bits 16+4s..) booked on
+    // SIMD s of that CU.  A workgroup whose waves sit on SIMDs (s0, s1) books (model, coder) =
+    // (s0, s1), or (s1, s0) when that collides with fewer roles already booked, and returns its
+    // booking when its coder wave ends.  Greedy, so not always perfect, but on an idle chip the
+    // dispatcher's own choice is kept and after a compaction every SIMD still gets (1, 1).
+    uint32_t claim_delta = 0; // (a VGPR on purpose: it is live across the whole kernel)
+    {
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        // (the last 16 bytes of the ring: the model wave writes there only after the first hand-off)
+        volatile uint32_t *book = reinterpret_cast<volatile uint32_t *>(ring) + kRingBytes / 4 - 4;
+        if (lane == 0)
+            book[w8] = (hwid >> 4) & 3u; // my SIMD
+        __syncthreads();
+        uint32_t *claim_word = a.claims + (((xcc & 7u) << 8) | ((hwid >> 8) & 0xFFu)); // (xcc, se, sh, cu)
+        if (w8 == 0 && lane == 0) {
+            const uint32_t s0 = book[0], s1 = book[1];
+            const uint32_t straight = (1u << (4 * s0)) | (1u << (16 + 4 * s1));
+            const uint32_t flipped  = (1u << (4 * s1)) | (1u << (16 + 4 * s0));
+            uint32_t       old      = __hip_atomic_load(claim_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t       flip;
+            do {
+                const uint32_t cs = ((old >> (4 * s0)) & 15u) + ((old >> (16 + 4 * s1)) & 15u);
+                const uint32_t cf = ((old >> (4 * s1)) & 15u) + ((old >> (16 + 4 * s0)) & 15u);
+                flip              = cf < cs;
+            } while (!__hip_atomic_compare_exchange_strong(claim_word, &old, old + (flip ? flipped : straight),
+                                                           __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            book[2] = flip;
+            book[3] = flip ? flipped : straight;
+        }
+        __syncthreads();
+        role ^= __builtin_amdgcn_readfirstlane(book[2]);
+        claim_delta = book[3];
+    }
+#else
     __syncthreads();
+#endif
+    const uint32_t wave = role; // 0 = model, 1 = coder
     Tree<true> T;
     T.init(lds, lane);
-    uint2 *ring = reinterpret_cast<uint2 *>(lds + Tree<true>::kDwords);
 
     uint32_t len = 0;
     if (live) {
@@ -585,7 +639,7 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
     __syncthreads(); // the model wave's last updates are in LDS before the tail reads the tree
 #ifdef REDUX_STAMPS
     if (lane == 0) {
-        lds64p st = (lds64p)(uintptr_t)(wave * 32);
+        lds64p st = (lds64p)(uintptr_t)(w8 * 32);
         unsigned long long *dstp = reinterpret_cast<unsigned long long *>(a.slots + a.nblocks * a.slot_bytes) + (blockIdx.x * 2 + wave) * 4;
         uint32_t hwid, xcc; // where this wave ran: (xcc, se, sh, cu, simd) -- the pair needs one model and one coder wave per SIMD
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -613,6 +667,15 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
             a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
         }
     }
+#if REDUX_CLAIMS
+    if (lane == 0) { // waves do not migrate: the same CU as at the start
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_fetch_sub(a.claims + (((xcc & 7u) << 8) | ((hwid >> 8) & 0xFFu)), claim_delta, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
 }
 
 // ======================================================================================
@@ -1920,7 +1983,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.off_rc    = 0;
     g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
     g.off_mode  = align_up(g.off_sizes + g.nblocks * 4, 256); // one word: 0 linear slots, != 0 row-major group areas
-    g.off_slots = g.off_mode + 256;
+    g.off_slots = g.off_mode + 256 + kClaimWords * 4; // mode word, then k_encode_pair's role book
     // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode
     g.off_trees = align_up(g.off_slots + ((g.nblocks + 63) / 64 * 64 + 1) * g.slot_bytes + (g.nblocks + 63) / 64 * 128, 256);
     g.total     = g.off_trees + g.nblocks * g.tree_bytes;
@@ -1999,7 +2062,7 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     hipStream_t s  = (hipStream_t)stream;
     uint8_t    *ws = (uint8_t *)d_workspace;
 
-    HIP_TRY(hipMemsetAsync(ws + g.off_mode, 0, 4, s)); // linear slots unless the pair kernel runs (below)
+    HIP_TRY(hipMemsetAsync(ws + g.off_mode, 0, 256 + kClaimWords * 4, s)); // linear slots unless the pair kernel runs (below); empty role book
     if (g.any) {
         AnyEncArgs aa;
         aa.in         = (const uint8_t *)d_in;
@@ -2035,6 +2098,7 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     a.nfreeze    = g.nfreeze;
     a.code_bits  = p->code_bits;
     a.aligned16  = ((((uintptr_t)d_in) & 15) == 0 && (block_size & 15) == 0) ? 1 : 0;
+    a.claims     = (uint32_t *)(ws + g.off_mode + 256);
     // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset;
     // otherwise (giant blocks, whole-stream mode) one block per wave.
     a.lanes = (64ull * g.slot_bytes < (1ull << 32) && 64ull * block_size < (1ull << 32)) ? 64u : 1u;

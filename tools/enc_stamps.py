@@ -33,7 +33,7 @@ if (stride // 128) % 2 == 0:
     stride += 128
 al = lambda v, a: (v + a - 1) // a * a
 rc_n = BLOCK + 1 + 32
-off_slots = al(al(rc_n * 8, 256) + nb * 4, 256) + 256  # + the mode word
+off_slots = al(al(rc_n * 8, 256) + nb * 4, 256) + 256 + 8192  # + the mode word and the role book
 off = enc.ws_off + off_slots + nb * stride
 raw = enc.ws[off: off + 1024 * 2 * 32].cpu().numpy().view(np.uint64).reshape(1024, 2, 4)
 print(f"kernel {e0.elapsed_time(e1):.2f} ms (stamped build)")

@@ -14,6 +14,12 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursi
     for row in csv.DictReader(open(f)):
         print("  %-60s calls=%s total_ns=%s avg_ns=%s pct=%s" % (row.get("Name", "")[:60], row.get("Calls"),
               row.get("TotalDurationNs"), row.get("AverageNs"), row.get("Percentage")))
+for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if sub in r["Kernel_Name"]]
+    if d:
+        k = min(10, len(d))
+        print("== %s: %d launches matching %s, ms each: %s" % (os.path.relpath(f, root), len(d), sub, " ".join("%.2f" % x for x in d)))
+        print("   mean of all %.3f ms; mean of the last %d (the timed steps of the default bench) %.3f ms" % (sum(d) / len(d), k, sum(d[-k:]) / k))
 acc = defaultdict(list)
 for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
     for row in csv.DictReader(open(f)):
