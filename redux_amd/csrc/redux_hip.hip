@@ -930,6 +930,9 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
 #ifndef REDUX_DEC_DUP
 #define REDUX_DEC_DUP 0
 #endif
+#ifdef REDUX_DEC_CENSUS // diagnostic build: where each decode wave ran (tools/dec_census.py)
+__device__ uint32_t g_dec_hw[4096];
+#endif
 #ifdef REDUX_DEC_STAMPS // diagnostic build: cycle stamps inside the lock-step step (tools/dec_stamps.sh)
 __device__ uint64_t g_dec_ts[8];
 #define DEC_STAMP(i, dep)                                                                                              \
@@ -1311,6 +1314,14 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
     // symbol, collapses to low == high or runs out of stream (one v_or3 + one compare on sign
     // bits), it is committed without predication; otherwise the careful per-lane commit runs.
     const uint32_t pfast = capn < nfreeze ? capn : nfreeze;
+#ifdef REDUX_DEC_CENSUS
+    if (lane == 0 && blockIdx.x < 4096) {
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_dec_hw[blockIdx.x] = 0x80000000u | ((xcc & 0xFu) << 16) | (hwid & 0xFFFFu);
+    }
+#endif
 #ifdef REDUX_DEC_STAMPS
     uint64_t dec_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dec_t0 = clock64();
 #endif
@@ -2330,6 +2341,12 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     return REDUX_OK;
 }
 
+#ifdef REDUX_DEC_CENSUS
+extern "C" int redux_debug_dec_census(uint32_t *out4096)
+{
+    return (int)hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_dec_hw), 4096 * 4);
+}
+#endif
 #ifdef REDUX_DEC_STAMPS
 extern "C" int redux_debug_dec_stamps(uint64_t *out8)
 {
