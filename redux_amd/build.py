@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libredux_hip.so")
 SOURCES = ["redux_hip.hip"]
-DEPS = ["redux_hip.hip", "redux_coder.hpp", "zipf_table.inc", os.path.join("..", "..", "include", "redux_hip.h")]
+DEPS = sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "redux_hip.h")]
 
 
 def needs_build():

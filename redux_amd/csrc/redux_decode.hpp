@@ -1,0 +1,818 @@
+// redux_decode.hpp -- decode kernels of the MI355X block coder (gfx950 only).
+//
+//   k_decode<U16,FIXUP>  one wave per 64 blocks, per-lane control flow (general form)
+//   k_decode_lock<CB32>  default: all 64 lanes in lock-step, stream ring in LDS, top tree levels in VGPRs
+//   k_rcp_check          device-side exhaustive check of the reciprocal bound k_decode_lock relies on
+//
+// Included by redux_hip.hip (one translation unit).
+#pragma once
+
+#include "redux_coder.hpp"
+
+#include "../../include/redux_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace redux {
+
+// ======================================================================================
+// decode
+// ======================================================================================
+struct DecArgs {
+    const uint8_t  *in;
+    const uint64_t *in_offsets; // nblocks + 1
+    uint64_t        nblocks;
+    uint8_t        *out;        // block b at out + b*block_size
+    uint32_t       *out_sizes;
+    int32_t        *status;
+    const double   *rc;
+    uint32_t        block_size;
+    uint32_t        nfreeze;
+    uint32_t        code_bits;
+    uint32_t        aligned4;   // 1: out and block_size are 4-byte multiples; 2: 16-byte multiples
+    uint64_t       *in_used;    // optional: bytes of each stream the reader fetched (ByteCount, bitio/mod.rs:71)
+};
+
+// BitReader (bitio/mod.rs:78-120) as a 64-bit look-ahead register: the `cnt` not yet
+// consumed bits sit in the TOP of `bits`; refills are whole aligned dwords, big-endian
+// (MSB-first stream).  Reads past the stream's last dword yield zeros; running past the end
+// is detected by the consumed-bit count, exactly where read_bits would return Err(Eof).
+struct BitIn {
+    uint64_t        bits;
+    uint32_t        cnt;
+    uint32_t        nextw; // the following dword, already loaded: a refill never waits on memory
+    const uint32_t *rp, *end;
+
+    __device__ __forceinline__ uint32_t fetch()
+    {
+        const uint32_t w = rp < end ? *rp : 0u;
+        rp++;
+        return w;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (cnt <= 32) {
+            bits |= (uint64_t)__builtin_bswap32(nextw) << (32 - cnt);
+            cnt += 32;
+            nextw = fetch(); // consumed by the NEXT refill of this lane, several symbols from now
+        }
+    }
+    __device__ __forceinline__ void init(const uint8_t *sp, uint64_t size)
+    {
+        const uintptr_t a = (uintptr_t)sp & ~(uintptr_t)3;
+        const uint32_t  skip = (uint32_t)((uintptr_t)sp & 3) * 8;
+        rp    = reinterpret_cast<const uint32_t *>(a);
+        end   = reinterpret_cast<const uint32_t *>(((uintptr_t)sp + size + 3) & ~(uintptr_t)3);
+        bits  = 0;
+        cnt   = 0;
+        nextw = fetch();
+        refill();
+        bits <<= skip;
+        cnt -= skip;
+        refill();
+    }
+    // next n (<= 32) bits, MSB first
+    __device__ __forceinline__ uint32_t take(uint32_t n)
+    {
+        const uint32_t v = (uint32_t)((bits >> 1) >> (63 - n));
+        bits <<= n;
+        cnt -= n;
+        refill();
+        return v;
+    }
+};
+
+template <bool U16, bool FIXUP>
+__global__ void __launch_bounds__(64) k_decode(DecArgs a)
+{
+    __shared__ uint32_t lds[Tree<U16>::kDwords];
+    constexpr int  KS   = Tree<U16>::kShift;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
+    const bool     live = blk < a.nblocks;
+
+    for (uint32_t i = lane; i < Tree<U16>::kDwords / 4; i += 64)
+        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    Tree<U16> T;
+    T.init(lds, lane);
+
+    const uint32_t cb = a.code_bits, sh = 32 - cb;
+    uint64_t       size = 0;
+    const uint8_t *sp   = a.in;
+    if (live) {
+        const uint64_t o0 = a.in_offsets[blk];
+        size              = a.in_offsets[blk + 1] - o0;
+        sp                = a.in + o0;
+    }
+    const uint64_t stream_bits = size * 8;
+    uint8_t       *dst         = a.out + (live ? blk : 0) * (uint64_t)a.block_size;
+    const uint32_t capn        = a.block_size;
+    const rc_ptr   rcp         = (rc_ptr)a.rc;
+
+    BitIn B;
+    B.init(sp, live ? size : 0);
+    // decompress_symbol's first call pulls code_bits bits into `pending` (codec.rs:124-127).
+    // W holds that value left-aligned (value << sh), like low/high.
+    uint32_t W        = B.take(cb) << sh;
+    uint64_t consumed = cb;
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    int32_t  st   = REDUX_OK;
+    bool     done = !live;
+    if (live && consumed > stream_bits) { // stream shorter than code_bits: Err(Eof) at once
+        st   = REDUX_EOF;
+        done = true;
+    }
+    uint32_t n_out = 0;
+    uint32_t obuf  = 0;
+
+    for (uint32_t p = 0;; p++) {
+        if (__builtin_amdgcn_readfirstlane(__ballot(!done) == 0))
+            break;
+        const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
+        const double   rc  = rcp[nup];
+        const uint32_t c   = 257u + nup;
+        if (!done) {
+            // value = ((pending - low + 1) * count - 1) / range      (codec.rs:129-131)
+            const uint32_t R1  = (high - low) >> sh;
+            const uint32_t Vd  = (W - low) >> sh;
+            const uint64_t num = ((uint64_t)Vd + 1) * c - 1;
+            const double   xd  = (double)R1 + 1.0;
+            uint32_t       v   = (uint32_t)((double)num / xd);
+            {
+                const int64_t r = (int64_t)(num - ((uint64_t)v * R1 + v));
+                if (r < 0)
+                    v--;
+                else if ((uint64_t)r > (uint64_t)R1)
+                    v++;
+            }
+            // get_symbol (adaptive_tree.rs:115-136): the descent probes exactly the nodes
+            // e_b(s); the same eight values give cum(s+1), and the levels where the descent
+            // went left (bit clear) are the ones update(s+1) increments.
+            uint32_t lo, hi;
+            bool     is_eof = false;
+            uint32_t s      = 0;
+            if (v >= c - 1) { // first probe: tree[256] = 256 + #updates = count - 1
+                is_eof = true;
+                lo     = c - 1;
+                hi     = c;
+            } else {
+                uint32_t x[8], ea[8];
+                uint32_t i = 0, rem = v;
+#pragma unroll
+                for (int b = 7; b >= 0; b--) {
+                    ea[b] = (i << KS) | T.A[b];
+                    x[b]  = T.node(ea[b]);
+                    const uint32_t tv = (1u << b) + x[b];
+                    if (rem >= tv) {
+                        i |= 1u << b;
+                        rem -= tv;
+                    }
+                }
+                s  = i;
+                lo = v - rem;
+                const uint32_t m  = s + 1;
+                uint32_t       hs = m;
+#pragma unroll
+                for (int b = 0; b < 8; b++)
+                    hs += ((m >> b) & 1u) ? x[b] : 0u;
+                hi = hs + (s == 255u ? nup : 0u);
+                if (p < a.nfreeze) {
+#pragma unroll
+                    for (int b = 0; b < 8; b++)
+                        T.add(ea[b], ((s >> b) & 1u) ? 0u : T.inc);
+                }
+            }
+            if (is_eof) { // codec.rs:136-138: returns before any renormalisation
+                done = true;
+            } else if (p >= capn) {
+                st   = REDUX_OUTPUT_TOO_SMALL;
+                done = true;
+            } else {
+                const double   Y     = __builtin_fma((double)R1, rc, rc);
+                const uint32_t nlow  = low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
+                const uint32_t nhigh = low + (scale_div<FIXUP>(R1, Y, hi, c) << sh) - 1u;
+                const uint32_t xx    = nlow ^ nhigh;
+                const uint32_t k     = xx ? (uint32_t)__builtin_clz(xx) : 32u;
+                const uint32_t low2  = (uint32_t)((uint64_t)nlow << k);
+                const uint32_t ih2   = (uint32_t)((uint64_t)(~nhigh) << k);
+                const uint32_t t     = (low2 & ih2) << 1;
+                const uint32_t j     = (uint32_t)__builtin_clz(~t);
+                low                  = (low2 << j) & 0x7FFFFFFFu;
+                high                 = ~((ih2 << j) & 0x7FFFFFFFu);
+                const uint32_t n     = k + j; // bits pulled by get_bit (codec.rs:157)
+                consumed += n;
+                if (consumed > stream_bits) { // read_bits would hit Err(Eof) (bitio/mod.rs:107)
+                    st   = REDUX_EOF;
+                    done = true;
+                } else {
+                    // k E1/E2 steps shift the value left (codec.rs:143-146 + :155-157); each of
+                    // the j E3 steps then drops the bit just below the top one (:147-151).  On
+                    // the 64-bit image [value | n new bits] that is: shift by k, remember the top
+                    // bit, shift by j more, put the remembered top bit back.
+                    const uint32_t nb   = B.take(n);
+                    const uint64_t comb = ((uint64_t)W << 32) | ((uint64_t)nb << (32 + sh - n));
+                    const uint64_t c1   = comb << k;
+                    const uint64_t c2   = c1 << j;
+                    W = (((uint32_t)(c2 >> 32) & 0x7FFFFFFFu) | ((uint32_t)(c1 >> 32) & 0x80000000u)) &
+                        (0xFFFFFFFFu << sh);
+                    // emit the symbol (write_bits(symbol, 8), codec.rs:171)
+                    if (a.aligned4) {
+                        obuf |= s << (8 * (p & 3));
+                        if ((p & 3) == 3) {
+                            *reinterpret_cast<uint32_t *>(dst + (p & ~3u)) = obuf;
+                            obuf = 0;
+                        }
+                    } else {
+                        dst[p] = (uint8_t)s;
+                    }
+                    n_out = p + 1;
+                }
+            }
+        }
+    }
+    if (live) {
+        if (a.aligned4)
+            for (uint32_t i = n_out & ~3u; i < n_out; i++)
+                dst[i] = (uint8_t)(obuf >> (8 * (i & 3)));
+        a.out_sizes[blk] = n_out;
+        a.status[blk]    = st;
+        if (a.in_used) { // the reader fetches whole bytes, and never past the end of the stream
+            const uint64_t used = ((uint64_t)consumed + 7) / 8;
+            a.in_used[blk]      = used < size ? used : size;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// Lock-step decoder (the default for u16 trees, count < 2^17).  Same results as k_decode; what changes is the instruction count of a step, which is what a lone wave
+// per SIMD pays for:
+//   * own tree layout: lane l owns dword column l; dword k of the column holds nodes 2k (low
+//     half) and 2k+1 (high half): byte address (k << 8) | 4*l.  Levels 1-7 are even nodes, so
+//     their half is static (low); level 0 is always a high half.  No per-lane half select.
+//   * the descent keeps q = ~rem.  For a node value t, q2 = q + t is ~(rem - t): its top bit
+//     is the "go right" flag, the new q is max_u32(q, q2) (q2 wraps to a small number when the
+//     probe fails), and the flags are shifted into the symbol by v_alignbit.  cum(s+1) falls
+//     out of the same probes: it is the upper boundary of the LAST level where the descent
+//     went left, i.e. v + 1 + min_u32 over the levels of q2 (failed probes give the small
+//     values and the boundary only shrinks on the way down; the virtual root probe against
+//     tree[256] = count - 1 seeds the minimum).  Five VALU ops per level, no second masked sum.
+//   * all 64 lanes stay in lock-step while nothing exceptional happens: the step is computed
+//     for every lane, and ONE ballot (EOF symbol, low == high, stream exhausted) decides whether
+//     it is committed without predication.  The first exceptional step leaves the fast loop
+//     with nothing committed and the predicated loop below redoes it and finishes the blocks.
+//   * the bit reader refills without a branch: the dword at rpo is (re)loaded every step, a
+//     whole step before it can be needed, and consumed when fewer than 33 bits are left.
+// --------------------------------------------------------------------------------------
+#ifndef REDUX_DEC_DUP
+#define REDUX_DEC_DUP 0
+#endif
+#ifdef REDUX_DEC_CENSUS // diagnostic build: where each decode wave ran (tools/dec_census.py)
+__device__ uint32_t g_dec_hw[4096];
+#endif
+#ifdef REDUX_DEC_STAMPS // diagnostic build: cycle stamps inside the lock-step step (tools/dec_stamps.sh)
+__device__ uint64_t g_dec_ts[8];
+#define DEC_STAMP(i, dep)                                                                                              \
+    {                                                                                                                  \
+        uint64_t t_;                                                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");                        \
+        dec_ts[i] += t_ - dec_t0;                                                                                      \
+        dec_t0 = t_;                                                                                                   \
+    }
+#define DEC_STAMP_ARGS , uint64_t (&dec_ts)[8], uint64_t &dec_t0
+#define DEC_STAMP_PASS , dec_ts, dec_t0
+#else
+#define DEC_STAMP(i, dep)
+#define DEC_STAMP_ARGS
+#define DEC_STAMP_PASS
+#endif
+
+struct DecFound {
+    uint32_t s, lo, hi;
+    uint32_t eofq; // top bit set: v >= count - 1, the first probe of get_symbol fails -> EOF (adaptive_tree.rs:116)
+};
+
+// The seven nodes of levels 7, 6, 5 (128; 64, 192; 32, 96, 160, 224) are at fixed positions,
+// so a decoder lane keeps them in VGPRs: the first three probes of every descent need no LDS
+// round trip, and their updates are compare + add-with-carry instead of LDS atomics.  (A
+// lock-step decoder wave is alone on its SIMD and the four waves of a CU share one LDS
+// pipeline: 8 cycles per ds_read_b32 and 16 per ds_add, tools/ubench/lone.hip.)
+struct DecTop {
+    uint32_t n128, n64, n192, n32, n96, n160, n224; // full tree values (lowbit + increments): u32, no overflow to think about
+};
+__device__ __forceinline__ DecTop dec_top_new() { return {128u, 64u, 64u, 32u, 32u, 32u, 32u}; }
+
+// get_symbol (adaptive_tree.rs:115-136) + the high end of get_frequency (:105-113), layout above.
+// Safe for any v (lanes that are already done run it on garbage): every address stays inside
+// the 32 KiB tree.
+__device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, const DecTop &T, uint32_t v,
+                                               uint32_t c DEC_STAMP_ARGS)
+{
+    auto ld = [&](uint32_t byte) { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + byte); };
+    uint32_t q = ~v, hq = q + (c - 1u), bits = 0, q2;
+    DecFound f;
+    f.eofq = hq;
+#define REDUX_DEC_LEVEL(t)                                                                                             \
+    left = __builtin_uadd_overflow(q, (t), &q2); /* carries exactly when the probe fails (rem < t: go left) */          \
+    bits = __builtin_amdgcn_alignbit(bits, q2, 31);                                                                    \
+    q    = q > q2 ? q : q2;                                                                                            \
+    hq   = hq < q2 ? hq : q2;
+    bool left;
+    // levels 7, 6, 5: registers (full tree values: lowbit + increments)
+    REDUX_DEC_LEVEL(T.n128)
+    const uint32_t x6 = left ? T.n64 : T.n192, c5l = left ? T.n32 : T.n160, c5r = left ? T.n96 : T.n224;
+    REDUX_DEC_LEVEL(x6)
+    const uint32_t x5 = left ? c5l : c5r;
+    REDUX_DEC_LEVEL(x5)
+    DEC_STAMP(2, bits)
+    // round B: levels 4, 3 under the prefix i = bits << 5: nodes i+16; i+8, i+24 (three dwords)
+    uint32_t       ib  = ((bits & 7u) << 12) | L;
+    const uint32_t w16 = ld(ib + (16u << 7));
+    const uint32_t w8 = ld(ib + (8u << 7)), w24 = ld(ib + (24u << 7));
+    REDUX_DEC_LEVEL((w16 & 0xFFFFu) + 16u)
+    const uint32_t x3 = left ? w8 : w24;
+    REDUX_DEC_LEVEL((x3 & 0xFFFFu) + 8u)
+    DEC_STAMP(3, bits)
+    // round C: levels 2, 1, 0 under i = bits << 3.  The four dwords i/2 .. i/2+3 hold nodes
+    // (i, i+1), (i+2, i+3), (i+4, i+5), (i+6, i+7): all seven candidates.
+    ib                = ((bits & 31u) << 10) | L;
+    const uint32_t d0 = ld(ib), d1 = ld(ib + 256u), d2 = ld(ib + 512u), d3 = ld(ib + 768u);
+    REDUX_DEC_LEVEL((d2 & 0xFFFFu) + 4u) // node i+4
+    const uint32_t e1 = left ? d1 : d3;  // level 1: node i+2 or i+6 (low halves)
+    const uint32_t e0 = left ? d0 : d2;  // level 0 if level 1 goes left: node i+1 or i+5 (high halves)
+    REDUX_DEC_LEVEL((e1 & 0xFFFFu) + 2u)
+    const uint32_t x0 = left ? e0 : e1;  // ... if it goes right: node i+3 or i+7, the high half of level 1's dword
+    REDUX_DEC_LEVEL((x0 >> 16) + 1u)
+    DEC_STAMP(4, bits)
+#undef REDUX_DEC_LEVEL
+    f.s  = bits & 0xFFu;
+    f.lo = v + q + 1u;  // v - rem
+    f.hi = v + hq + 1u; // upper boundary of the last level that went left
+    return f;
+}
+
+// update(s+1) (adaptive_tree.rs:83-92): +1 on the levels where bit b of s is clear.  Levels 7-5
+// live in registers: node e of level b is incremented iff s lies in [e - 2^b, e), an unsigned
+// range compare + add-with-carry; levels 4-0 are fire-and-forget ds_add_u32.
+__device__ __forceinline__ void dec_update(uint32_t *lds, const uint32_t (&A)[8], DecTop &T, uint32_t s)
+{
+    T.n128 += s < 128u ? 1u : 0u;
+    T.n64 += s < 64u ? 1u : 0u;
+    T.n192 += (s - 128u) < 64u ? 1u : 0u;
+    T.n32 += s < 32u ? 1u : 0u;
+    T.n96 += (s - 64u) < 32u ? 1u : 0u;
+    T.n160 += (s - 128u) < 32u ? 1u : 0u;
+    T.n224 += (s - 192u) < 32u ? 1u : 0u;
+    const uint32_t ss = s << 7, ns = ~s;
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+        const uint32_t keep = b ? (((0xFFu << b) & 0xFFu) << 7) : (0xFEu << 7);
+        const uint32_t addr = (ss & keep) | A[b];
+        const uint32_t inc  = b ? ((ns >> b) & 1u) : ((ns & 1u) << 16);
+        __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + addr), inc, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// value = floor(((V - low + 1) * count - 1) / range) (codec.rs:129-131) in f64.  Numerator nd
+// (< 2^49) and range xd (an integer in [1, 2^32]) are exact.  r' = v_rcp_f64(xd) * (1 - 2^-22):
+// the raw v_rcp_f64 of gfx950 is within 2^-24 (measured: 2^-24.4) of 1/xd for EVERY integer xd in [1, 2^32]
+// (checked exhaustively on the device by redux_debug_rcp_check, tests/test_gpu_parity.py), so
+// (1 - 2^-21)/xd <= r' <= 1/xd and, the quotient being < 2^17.1, the truncated product is q or
+// q - 1; one exact f64 remainder (fma; v * xd < 2^50) adds the 1 back.
+__device__ __forceinline__ uint32_t dec_value(double R1d, uint32_t Vd, double cd, double cdm1)
+{
+    const double xd = R1d + 1.0;
+    const double nd = __builtin_fma((double)Vd, cd, cdm1); // (Vd+1)*c - 1, exact (< 2^49)
+#ifdef REDUX_DEC_NEWTON // the older form: one Newton step, bias 2^-40
+    double r = __builtin_amdgcn_rcp(xd);
+    r        = __builtin_fma(__builtin_fma(-xd, r, 1.0), r, r);
+    uint32_t v = (uint32_t)(nd * (r * 0.99999999999909050530));
+#else
+    uint32_t v = (uint32_t)(nd * (__builtin_amdgcn_rcp(xd) * 0.99999976158142089844)); // 1 - 2^-22
+#endif
+    v += __builtin_fma(-(double)v, xd, nd) >= xd ? 1u : 0u;
+    return v;
+}
+
+// exhaustive check behind dec_value: max over all integers x in [lo, hi] of |rcp(x) * x - 1|, as
+// the f64 bit pattern of the maximum (positive doubles order like their bits)
+__global__ void k_rcp_check(uint64_t lo, uint64_t hi, unsigned long long *max_bits)
+{
+    double m = 0.0;
+    for (uint64_t x = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x <= hi; x += (uint64_t)gridDim.x * blockDim.x) {
+        const double xd = (double)x;
+        const double e  = __builtin_fabs(__builtin_fma(__builtin_amdgcn_rcp(xd), xd, -1.0));
+        m               = e > m ? e : m;
+    }
+    atomicMax(max_bits, (unsigned long long)__double_as_longlong(m));
+}
+
+struct DecLane {
+    uint32_t low, ihigh; // ihigh = ~high; both left-aligned as in EncState
+    uint32_t W;          // code value (codec.rs `pending`), left-aligned
+    uint64_t bbits;      // upcoming stream bits, left-aligned
+    uint32_t bcnt;       // how many of them are valid
+    uint32_t consumed;   // stream bits pulled so far
+    uint32_t obuf;
+    uint32_t n_out;      // symbols emitted: set when the block finishes (a live lane has emitted one per step)
+    uint32_t dflag;      // 0x80000000 once the block is finished (EOF symbol or error)
+    uint32_t sbits;      // stream length in bits while the block is live, 0 once it is finished
+    int32_t  st;
+};
+
+// Per-lane, predicated end of a step: decompress_symbol after the model answered
+// (codec.rs:133-161) + decompress_stream's emission (:170-172).  `may_update`: the model is not
+// frozen; `room`: p < block capacity.
+template <bool CB32>
+__device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const DecFound &f, uint32_t *lds, const uint32_t (&A)[8],
+                                                   uint32_t R1, double R1d, double rc, uint32_t c, uint32_t sh,
+                                                   uint32_t stream_bits, uint32_t p, bool may_update, bool room,
+                                                   bool aligned4, uint8_t *dst)
+{
+    if ((int32_t)S.dflag < 0)
+        return;
+    if ((int32_t)f.eofq < 0) { // codec.rs:136-138: returns before any renormalisation
+        S.dflag = 0x80000000u;
+        S.sbits = 0;
+        S.n_out = p;
+        return;
+    }
+    if (!room) {
+        S.st    = REDUX_OUTPUT_TOO_SMALL;
+        S.dflag = 0x80000000u;
+        S.sbits = 0;
+        S.n_out = p;
+        return;
+    }
+    if (may_update)
+        dec_update(lds, A, T, f.s);
+    const double   Y      = __builtin_fma(R1d, rc, rc);
+    const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
+    const uint32_t nihigh = 0u - (S.low + (scale_div<false>(R1, Y, f.hi, c) << sh));
+    const uint32_t xx     = ~(nlow ^ nihigh);
+    const uint32_t k      = xx ? (uint32_t)__builtin_clz(xx) : 32u;
+    const uint32_t low2   = (uint32_t)((uint64_t)nlow << k);
+    const uint32_t ih2    = (uint32_t)((uint64_t)nihigh << k);
+    const uint32_t t2     = (low2 & ih2) << 1;
+    const uint32_t j      = (uint32_t)__builtin_clz(~t2);
+    S.low                 = (low2 << j) & 0x7FFFFFFFu;
+    S.ihigh               = (ih2 << j) & 0x7FFFFFFFu;
+    const uint32_t n      = k + j; // bits pulled by get_bit (codec.rs:157)
+    S.consumed += n;
+    if (S.consumed > stream_bits) { // read_bits would return Err(Eof) (bitio/mod.rs:107)
+        S.st    = REDUX_EOF;
+        S.dflag = 0x80000000u;
+        S.sbits = 0;
+        S.n_out = p;
+        return;
+    }
+    // [value | next 32 bits] << k, keep the top bit, << j, put it back (codec.rs:143-157)
+    const uint32_t nxt  = (uint32_t)(S.bbits >> 32);
+    const uint64_t comb = ((uint64_t)(S.W >> sh) << (32 + sh)) | ((uint64_t)nxt << sh);
+    const uint64_t c1   = comb << k;
+    const uint64_t c2   = c1 << j;
+    S.W = (((uint32_t)(c2 >> 32) & 0x7FFFFFFFu) | ((uint32_t)(c1 >> 32) & 0x80000000u)) & (0xFFFFFFFFu << sh);
+    S.bbits <<= n;
+    S.bcnt -= n;
+    if (aligned4)
+        S.obuf |= f.s << (8 * (p & 3));
+    else
+        dst[p] = (uint8_t)f.s;
+}
+
+template <bool CB32>
+__global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
+{
+    __shared__ uint32_t lds[128 * 64 + 32 * 64]; // tree (32 KiB) + stream ring (8 KiB): four groups fill the CU's 160 KiB
+    const uint32_t lane = threadIdx.x;
+    const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
+    const bool     live = blk < a.nblocks;
+
+    for (uint32_t i = lane; i < 128 * 64 / 4; i += 64)
+        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t L = lane * 4u;
+    uint32_t       A[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        A[b] = (b ? (1u << (b + 7)) : 0u) | L;
+        asm volatile("" : "+v"(A[b]));
+    }
+
+    const uint32_t cb = CB32 ? 32u : a.code_bits, sh = CB32 ? 0u : 32 - cb;
+    uint64_t       size = 0;
+    const uint8_t *sp   = a.in;
+    if (live) {
+        const uint64_t o0 = a.in_offsets[blk];
+        size              = a.in_offsets[blk + 1] - o0;
+        sp                = a.in + o0;
+    }
+    const uint32_t stream_bits = (uint32_t)(size * 8);
+    uint8_t       *dst         = a.out + (live ? blk : 0) * (uint64_t)a.block_size;
+    const uint32_t capn        = a.block_size;
+    const rc_ptr   rcp         = (rc_ptr)a.rc;
+    const uint32_t nfreeze     = a.nfreeze;
+    const bool     aligned4    = a.aligned4 != 0;
+    const bool     aligned16   = a.aligned4 == 2;
+
+    // Bit reader (bitio/mod.rs:78-120).  The stream is read as aligned dwords from a per-lane base.
+    // A lock-step wave waits for the SLOWEST of its 64 lanes on every vector-memory wait, and
+    // with 64 independent streams some lane misses to HBM nearly every step, so a load that is
+    // consumed one step later bounds the step at the memory latency (measured: 1700 cycles per
+    // step whatever the step computes).  Hence a ring of 32 dwords per lane in LDS, filled by
+    // the producer below (one 16-byte load per lane and group of four steps, retired into the
+    // ring a whole group later) and drained by the reader with LDS reads: `fetched` is always
+    // the dword at index rpo, read from the ring a step before it can be consumed.
+    //   * dword d of lane l: ring byte RB + ((d & 31) << 8) + 4l (conflict-free per-lane rows);
+    //   * chunk wr (dwords 4wr..4wr+3) is requested while 4wr - rpo <= 28, so its slot's old
+    //     content (chunk wr-8) is consumed; a step consumes < 1 dword, a group < 4: the ring
+    //     never runs dry (initial fill: 24 dwords);
+    //   * indices are clamped to the stream's last dword: bits past the end of a stream are
+    //     never USED (consuming them is the Eof error, detected by the bit count), so their
+    //     value does not matter, but the loads must stay inside the buffer.  A lane without a
+    //     stream reads the offsets table instead (always mapped) and is done from the start.
+    typedef const __attribute__((address_space(1))) uint32_t *gptr;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4 *gptr4;
+    const bool      has    = live && size > 0;
+    const uintptr_t sp_abs = (uintptr_t)sp;
+    const gptr      gin    = has ? (gptr)(sp_abs & ~(uintptr_t)3) : (gptr)(uintptr_t)a.in_offsets;
+    const uint32_t  rpo_last = has ? (uint32_t)(((((sp_abs + size + 3) & ~(uintptr_t)3) - (sp_abs & ~(uintptr_t)3)) >> 2) - 1) : 0u;
+    const uint32_t  skip   = has ? (uint32_t)(sp_abs & 3) * 8 : 0u;
+    auto rd = [&](uint32_t o) { return gin[o < rpo_last ? o : rpo_last]; };
+    constexpr uint32_t RB = 128 * 64 * 4;
+    auto ring_write = [&](uint32_t chunk, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+        uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + RB + ((chunk & 7u) << 10) + L);
+        q[0] = x0; q[64] = x1; q[128] = x2; q[192] = x3;
+    };
+    auto ring_read = [&](uint32_t d) {
+        return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + RB + ((d & 31u) << 8) + L);
+    };
+    uint32_t rpo = 2, wr = 0;
+    DecLane  S;
+    {
+        uint32_t d0 = 0, d1 = 0;
+        for (; wr < 6; wr++) {
+            const uint32_t x0 = rd(4 * wr), x1 = rd(4 * wr + 1), x2 = rd(4 * wr + 2), x3 = rd(4 * wr + 3);
+            if (wr == 0) {
+                d0 = has ? __builtin_bswap32(x0) : 0u;
+                d1 = (has && rpo_last >= 1) ? __builtin_bswap32(x1) : 0u;
+            }
+            ring_write(wr, x0, x1, x2, x3);
+        }
+        S.bbits = (((uint64_t)d0 << 32) | d1) << skip;
+        S.bcnt  = 64 - skip;
+    }
+    uint32_t fetched = ring_read(rpo);
+    bool     pend = false; // a chunk is in flight: requested by the previous group, not yet in the ring
+    uint32_t pend_chunk = 0;
+    u32x4    ldq = {0, 0, 0, 0};
+    S.W = (uint32_t)((S.bbits >> 1) >> (63 - cb)) << sh; // codec.rs:124-127
+    S.bbits <<= cb;
+    S.bcnt -= cb;
+    S.consumed = cb;
+    S.low = 0; S.ihigh = 0;
+    S.st = REDUX_OK;
+    S.dflag = live ? 0u : 0x80000000u;
+    if (live && S.consumed > stream_bits) { // stream shorter than code_bits: Err(Eof) at once
+        S.st    = REDUX_EOF;
+        S.dflag = 0x80000000u;
+    }
+    S.sbits = (int32_t)S.dflag < 0 ? 0u : stream_bits;
+    S.n_out = 0;
+    S.obuf  = 0;
+    uint32_t stored = 0; // bytes [0, stored) of the block are in memory
+    uint32_t staged = 0; // bytes [stored, staged) are whole dwords waiting in oq (newest in .w)
+    uint4    oq     = make_uint4(0, 0, 0, 0);
+    uint32_t p      = 0;
+    DecTop   T      = dec_top_new();
+
+#define REDUX_DEC_READER                                                                                               \
+    {                                                                                                                  \
+        const bool     need = S.bcnt <= 32;                                                                            \
+        const uint64_t add  = (uint64_t)(need ? __builtin_bswap32(fetched) : 0u) << ((32 - S.bcnt) & 63);              \
+        S.bbits |= add;                                                                                                \
+        S.bcnt += need ? 32u : 0u;                                                                                     \
+        rpo += need ? 1u : 0u;                                                                                         \
+        fetched = ring_read(rpo);                                                                                      \
+    }
+    // Once per group of four steps, in this order (vmcnt counts loads AND stores, in order, so
+    // the one wait of a group must find nothing younger than a group in flight):
+    //   RETIRE  wait for the chunk requested a group ago and move it into the ring;
+    //   STORE   the four symbols the previous group produced;
+    //   REQUEST the next chunk.
+#define REDUX_DEC_RETIRE                                                                                               \
+    if (pend)                                                                                                          \
+        ring_write(pend_chunk, ldq.x, ldq.y, ldq.z, ldq.w);
+    // Output: a finished group's dword is staged; 16-byte aligned blocks get one 16-byte store per
+    // four groups (p is wave-uniform, so that is a scalar branch).  A 4-byte store every four steps
+    // per lane is what the L2's background cleaning of resident dirty lines turns into ten times
+    // the output in fabric writes (WRITE_SIZE 43e6 KiB for 4 GiB).
+#define REDUX_DEC_STORE                                                                                                \
+    if (aligned16) {                                                                                                   \
+        if ((int32_t)S.dflag >= 0 && p > staged) { /* a live lane has emitted p symbols */                             \
+            oq     = make_uint4(oq.y, oq.z, oq.w, S.obuf);                                                             \
+            S.obuf = 0;                                                                                                \
+            staged = p;                                                                                                \
+            if ((p & 15u) == 0) {                                                                                      \
+                *reinterpret_cast<uint4 *>(dst + (p - 16)) = oq;                                                       \
+                stored = p;                                                                                            \
+            }                                                                                                          \
+        }                                                                                                              \
+    } else if (aligned4 && (int32_t)S.dflag >= 0 && p > stored) {                                                      \
+        *reinterpret_cast<uint32_t *>(dst + (p - 4)) = S.obuf;                                                         \
+        S.obuf = 0;                                                                                                    \
+        stored = p;                                                                                                    \
+        staged = p;                                                                                                    \
+    }
+#define REDUX_DEC_REQUEST                                                                                              \
+    {                                                                                                                  \
+        const bool room = (int32_t)(4u * wr - rpo) <= 28;                                                              \
+        const bool tail = 4u * wr + 3u > rpo_last;                                                                     \
+        pend       = room;                                                                                             \
+        pend_chunk = wr;                                                                                               \
+        if (room && !tail)                                                                                             \
+            ldq = *reinterpret_cast<gptr4>(gin + 4u * wr);                                                             \
+        if (__builtin_amdgcn_ballot_w64(room && tail) != 0) {                                                          \
+            if (room && tail) {                                                                                        \
+                ldq.x = rd(4u * wr);                                                                                   \
+                ldq.y = rd(4u * wr + 1u);                                                                              \
+                ldq.z = rd(4u * wr + 2u);                                                                              \
+                ldq.w = rd(4u * wr + 3u);                                                                              \
+            }                                                                                                          \
+        }                                                                                                              \
+        wr += room ? 1u : 0u;                                                                                          \
+    }
+
+    // ---------------- lock-step groups of four symbols ----------------
+    // While p < min(capacity, freeze point) every step updates the model and has room for its
+    // symbol.  A step is computed for all 64 lanes; if no lane is finished, reaches the EOF
+    // symbol, collapses to low == high or runs out of stream (one v_or3 + one compare on sign
+    // bits), it is committed without predication; otherwise the careful per-lane commit runs.
+    const uint32_t pfast = capn < nfreeze ? capn : nfreeze;
+#ifdef REDUX_DEC_CENSUS
+    if (lane == 0 && blockIdx.x < 4096) {
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_dec_hw[blockIdx.x] = 0x80000000u | ((xcc & 0xFu) << 16) | (hwid & 0xFFFFu);
+    }
+#endif
+#ifdef REDUX_DEC_STAMPS
+    uint64_t dec_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dec_t0 = clock64();
+#endif
+    if (aligned4) {
+        double cdm1 = 256.0, cd = 257.0;
+        // The group's four reciprocals are loaded a group ahead with VECTOR loads (every lane the
+        // same 32 bytes), behind the ring's chunk request: their latency is covered by the one
+        // vmcnt wait of the next group.  A scalar load would share lgkmcnt with the LDS, return
+        // out of order and so sit in front of the next LDS wait wherever it is issued.
+        typedef double f64x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) f64x4 *grc4;
+        const grc4 rcv = (grc4)(uintptr_t)a.rc; // 256-byte aligned workspace, p a multiple of 4
+        f64x4      rcg = rcv[0], rcn;
+        asm volatile("" : "+v"(rcg)); // arrived before the loop: no in-loop wait inherits this load
+        for (; p + 4 <= pfast; p += 4) {
+            if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
+                break;
+            REDUX_DEC_RETIRE
+            REDUX_DEC_STORE
+            REDUX_DEC_REQUEST
+            rcn = rcv[(p >> 2) + 1]; // the table has 32 entries of slack (geometry())
+#pragma unroll
+            for (int K = 0; K < 4; K++) {
+                const double   rc = rcg[K];
+                const uint32_t c  = 257u + p + K;
+                REDUX_DEC_READER
+                DEC_STAMP(0, S.bcnt)
+                const uint32_t R1  = (~(S.ihigh + S.low)) >> sh;
+                const uint32_t Vd  = (S.W - S.low) >> sh;
+                const double   R1d = (double)R1;
+#if REDUX_DEC_DUP == 1 // timing experiments: run one part of the step twice, results unchanged
+                uint32_t Vd_ = Vd;
+                {
+                    const uint32_t v0 = dec_value(R1d, Vd, cd, cdm1);
+                    asm volatile("" : "+v"(Vd_) : "v"(v0));
+                }
+                const uint32_t v = dec_value(R1d, Vd_, cd, cdm1);
+#else
+                const uint32_t v   = dec_value(R1d, Vd, cd, cdm1);
+#endif
+                DEC_STAMP(1, v)
+#if REDUX_DEC_DUP == 2
+                uint32_t v_ = v;
+                {
+                    const DecFound f0 = dec_search(lds, L, T, v, c DEC_STAMP_PASS);
+                    asm volatile("" : "+v"(v_) : "v"(f0.s), "v"(f0.lo), "v"(f0.hi));
+                }
+                const DecFound f = dec_search(lds, L, T, v_, c DEC_STAMP_PASS);
+#else
+                const DecFound f   = dec_search(lds, L, T, v, c DEC_STAMP_PASS);
+#endif
+                // narrowing + renormalisation (codec.rs:133-161), all lanes
+                const double   Y      = __builtin_fma(R1d, rc, rc);
+#if REDUX_DEC_DUP == 3
+                uint32_t lo_ = f.lo;
+                {
+                    const uint32_t a0 = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
+                    const uint32_t b0 = 0u - (S.low + (scale_div<false>(R1, Y, f.hi, c) << sh));
+                    const uint32_t x0 = ~(a0 ^ b0);
+                    uint32_t       k0;
+                    asm("v_ffbh_u32 %0, %1" : "=v"(k0) : "v"(x0));
+                    const uint32_t t0 = ((a0 << (k0 & 31u)) & (b0 << (k0 & 31u))) << 1;
+                    const uint32_t j0 = (uint32_t)__builtin_clz(~t0);
+                    asm volatile("" : "+v"(lo_) : "v"(j0));
+                }
+                const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, lo_, c) << sh);
+#else
+                const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
+#endif
+                const uint32_t nihigh = 0u - (S.low + (scale_div<false>(R1, Y, f.hi, c) << sh));
+                const uint32_t xx     = ~(nlow ^ nihigh);
+                uint32_t       k;
+                asm("v_ffbh_u32 %0, %1" : "=v"(k) : "v"(xx)); // -1 (sign bit) for low == high
+                const uint32_t low2  = nlow << (k & 31u);
+                const uint32_t ih2   = nihigh << (k & 31u);
+                const uint32_t t2    = (low2 & ih2) << 1;
+                const uint32_t j     = (uint32_t)__builtin_clz(~t2);
+                const uint32_t n     = k + j;
+                const uint32_t cons2 = S.consumed + n;
+                const uint32_t e     = f.eofq | k | (S.sbits - cons2); // sbits is 0 for a finished lane, cons2 > 0
+                DEC_STAMP(5, e)
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)e < 0) == 0, 1)) {
+                    dec_update(lds, A, T, f.s);
+                    S.low      = (low2 << j) & 0x7FFFFFFFu;
+                    S.ihigh    = (ih2 << j) & 0x7FFFFFFFu;
+                    S.consumed = cons2;
+                    const uint32_t nxt  = (uint32_t)(S.bbits >> 32);
+                    const uint64_t comb = CB32 ? (((uint64_t)S.W << 32) | nxt) : (((uint64_t)S.W << 32) | ((uint64_t)nxt << sh));
+                    const uint32_t h2   = (uint32_t)((comb << n) >> 32);
+                    const uint32_t h1   = S.W << k;
+                    S.W = ((h2 & 0x7FFFFFFFu) | (h1 & 0x80000000u)) & (0xFFFFFFFFu << sh);
+                    S.bbits <<= n;
+                    S.bcnt -= n;
+                    S.obuf |= f.s << (8 * K);
+                } else {
+                    dec_commit_careful<CB32>(S, T, f, lds, A, R1, R1d, rc, c, sh, stream_bits, p + K, true, true, true, dst);
+                }
+                cdm1 = cd;
+                cd += 1.0;
+                DEC_STAMP(6, S.low + S.W)
+            }
+            rcg = rcn;
+        }
+    }
+#ifdef REDUX_DEC_STAMPS
+    if (blockIdx.x == 7 && lane == 0)
+        for (int i = 0; i < 8; i++)
+            g_dec_ts[i] = i < 7 ? dec_ts[i] : p;
+#endif
+    // ---------------- remaining steps (EOF symbol, frozen model, unaligned output) ----------------
+    for (;; p++) {
+        if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
+            break;
+        const uint32_t nup = p < nfreeze ? p : nfreeze;
+        const double   rc  = rcp[nup];
+        const uint32_t c   = 257u + nup;
+        if ((p & 3) == 0) {
+            REDUX_DEC_RETIRE
+            REDUX_DEC_STORE
+            REDUX_DEC_REQUEST
+        }
+        REDUX_DEC_READER
+        const uint32_t R1  = (~(S.ihigh + S.low)) >> sh;
+        const uint32_t Vd  = (S.W - S.low) >> sh;
+        const double   R1d = (double)R1;
+        const uint32_t v   = dec_value(R1d, Vd, (double)c, (double)(c - 1u));
+        const DecFound f   = dec_search(lds, L, T, v, c DEC_STAMP_PASS);
+        dec_commit_careful<CB32>(S, T, f, lds, A, R1, R1d, rc, c, sh, stream_bits, p, p < nfreeze, p < capn, aligned4, dst);
+    }
+#undef REDUX_DEC_READER
+#undef REDUX_DEC_RETIRE
+#undef REDUX_DEC_STORE
+#undef REDUX_DEC_REQUEST
+    if (live) {
+        if (aligned4) {
+            // the 0..3 staged dwords (oldest first: the last k components of oq), then the partial one
+            const uint32_t k = (staged - stored) >> 2;
+            const uint32_t comp[4] = {oq.x, oq.y, oq.z, oq.w};
+            for (uint32_t j = 0; j < k; j++) {
+                const uint32_t idx = 4 - k + j;
+                const uint32_t w   = idx == 0 ? comp[0] : idx == 1 ? comp[1] : idx == 2 ? comp[2] : comp[3];
+                *reinterpret_cast<uint32_t *>(dst + stored + 4 * j) = w;
+            }
+            for (uint32_t i = staged; i < S.n_out; i++)
+                dst[i] = (uint8_t)(S.obuf >> (8 * (i & 3)));
+        }
+        a.out_sizes[blk] = S.n_out;
+        a.status[blk]    = S.st;
+        if (a.in_used) { // the reader fetches whole bytes, and never past the end of the stream
+            const uint64_t used = ((uint64_t)S.consumed + 7) / 8;
+            a.in_used[blk]      = used < size ? used : size;
+        }
+    }
+}
+
+} // namespace redux

@@ -1,0 +1,676 @@
+// redux_encode.hpp -- encode kernels of the MI355X block coder (gfx950 only).
+//
+//   k_fill_rc            per-step reciprocal table 1/(257+i), biased up 4 ulp
+//   k_encode<U16,FIXUP>  one wave per 64 blocks (general form: u32 trees, unaligned input, giant blocks)
+//   k_encode_pair<..>    default: a model wave and a coder wave per 64 blocks, LDS ring between them
+//
+// Included by redux_hip.hip (one translation unit); the host side launches these from
+// redux_encode_slots_dev.
+#pragma once
+
+#include "redux_coder.hpp"
+
+#include "../../include/redux_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace redux {
+
+// ======================================================================================
+// reciprocal table
+// ======================================================================================
+__global__ void k_fill_rc(double *rc, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double r = 1.0 / (double)(257u + i); // correctly rounded IEEE division
+        rc[i] = __longlong_as_double(__double_as_longlong(r) + 4);
+    }
+}
+
+// ======================================================================================
+// encode
+// ======================================================================================
+struct EncArgs {
+    const uint8_t *in;
+    uint64_t       in_len;
+    uint64_t       nblocks;
+    uint8_t       *slots;
+    uint64_t       slot_bytes;
+    uint32_t      *sizes;
+    int32_t       *status;
+    const double  *rc;
+    uint32_t       block_size;
+    uint32_t       slot_cap;  // usable bytes of a slot
+    uint32_t       nfreeze;   // freq_max - 257: number of updates before the freeze
+    uint32_t       code_bits;
+    uint32_t       aligned16; // in and block_size are 16-byte multiples
+    uint32_t       lanes;     // live lanes per wave: 64, or 1 when 64 slots overflow 32-bit offsets
+    uint32_t      *claims;    // kClaimWords words, zero at launch: k_encode_pair's per-CU role book
+};
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t w = __shfl_xor(v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t w = __shfl_xor(v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// 16 consecutive symbols of every lane's block, all lanes alive, no EOF: the hot loop body.
+// UPD: the model is still adaptive for the whole chunk (updates so far = q = p + i);
+// otherwise it is frozen (adaptive_tree.rs:84) and nup = nfreeze for every symbol.
+// A pending run longer than 32 bits can add any number of bytes, so the chunk's byte budget
+// is guarded by the caller only for the common path (4 bytes per symbol) plus slack; the
+// careful path inside encode_symbol_fast is entered at most once per such run and the caller
+// re-checks the budget every chunk.
+template <bool U16, bool FIXUP, bool UPD>
+__device__ __forceinline__ void encode_chunk(const Tree<U16> &T, EncState &S, const uint4 cur, uint32_t p,
+                                             uint32_t nfreeze, rc_ptr rc, uint32_t sh, uint8_t *wdst)
+{
+    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+    double         r[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        r[i] = rc[UPD ? p + i : nfreeze];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t s   = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const uint32_t nup = UPD ? p + i : nfreeze; // wave-uniform
+        uint32_t       lo, hi;
+        T.template get_frequency<UPD>(s, nup, true, lo, hi);
+        encode_symbol_fast<FIXUP>(S, lo, hi, 257u + nup, r[i], sh, wdst);
+    }
+}
+
+template <bool U16, bool FIXUP>
+__global__ void __launch_bounds__(64) k_encode(EncArgs a)
+{
+    __shared__ uint32_t lds[Tree<U16>::kDwords];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t blk0 = (uint64_t)blockIdx.x * a.lanes; // wave-uniform
+    const uint64_t blk  = blk0 + lane;
+    const bool     live = lane < a.lanes && blk < a.nblocks;
+
+    for (uint32_t i = lane; i < Tree<U16>::kDwords / 4; i += 64)
+        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    Tree<U16> T;
+    T.init(lds, lane);
+
+    uint32_t len = 0;
+    if (live) {
+        const uint64_t rem = a.in_len - blk * a.block_size;
+        len                = rem < a.block_size ? (uint32_t)rem : a.block_size;
+    }
+    // wave-uniform bases (SGPR pairs) + 32-bit per-lane offsets
+    const uint8_t *wsrc  = a.in + blk0 * a.block_size;
+    const uint32_t soff  = live ? lane * a.block_size : 0u;
+    uint8_t       *wdst  = a.slots + blk0 * a.slot_bytes;
+    // Dead lanes of the last wave run the same instruction stream on block blk0's bytes and
+    // store into the spare slot behind the last real one, so the hot loop needs no predicate.
+    const uint32_t off0  = live ? lane * (uint32_t)a.slot_bytes : (uint32_t)(a.nblocks - blk0) * (uint32_t)a.slot_bytes;
+    const uint32_t limit = off0 + a.slot_cap;
+
+    // The lock-step loop covers [0, maxlen]; the unrolled path covers whole 16-byte chunks
+    // strictly below the shortest live block's last symbol.
+    const uint32_t minlen  = __builtin_amdgcn_readfirstlane(wave_min(live ? len : 0xFFFFFFFFu));
+    // bytes the unrolled path may add per chunk without any per-store check: 16 x 4 + slack
+    constexpr uint32_t kChunkBudget = 16 * 4 + 32;
+    const uint32_t maxlen  = __builtin_amdgcn_readfirstlane(wave_max(live ? len : 0u));
+    const uint32_t sh      = 32 - a.code_bits;
+    const uint32_t nfreeze = a.nfreeze;
+    const rc_ptr   rc      = (rc_ptr)a.rc;
+
+    EncState S;
+    enc_init(S, off0);
+
+    uint32_t p        = 0;
+    uint32_t main_end = 0;
+    if (a.aligned16 && minlen != 0xFFFFFFFFu && minlen > 16)
+        main_end = (minlen - 1) & ~15u;
+
+    if (main_end) {
+        // (A) adaptive chunks
+        const uint32_t a_end = main_end < (nfreeze & ~15u) ? main_end : (nfreeze & ~15u);
+        if (p < a_end) {
+            uint4 cur = *reinterpret_cast<const uint4 *>(wsrc + soff);
+            for (; p < a_end; p += 16) {
+                if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit)) {
+                    main_end = p; // a slot is nearly full: finish in the checked tail loop
+                    break;
+                }
+                uint4 nxt = cur;
+                if (p + 16 < a_end)
+                    nxt = *reinterpret_cast<const uint4 *>(wsrc + soff + p + 16);
+                encode_chunk<U16, FIXUP, true>(T, S, cur, p, nfreeze, rc, sh, wdst);
+                cur = nxt;
+            }
+        }
+        // (M) the one chunk that crosses the freeze point, symbol by symbol
+        if (p < main_end && p < nfreeze) {
+            const uint32_t m_end = p + 16;
+            for (; p < m_end; p++) {
+                const uint32_t nup = p < nfreeze ? p : nfreeze;
+                uint32_t       lo, hi;
+                T.template get_frequency<true>(wsrc[soff + p], nup, p < nfreeze, lo, hi);
+                encode_symbol<FIXUP>(S, lo, hi, 257u + nup, rc[nup], sh, false, wdst, limit);
+            }
+        }
+        // (F) frozen chunks: static model, no LDS writes
+        if (p < main_end) {
+            uint4 cur = *reinterpret_cast<const uint4 *>(wsrc + soff + p);
+            for (; p < main_end; p += 16) {
+                if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit)) {
+                    main_end = p;
+                    break;
+                }
+                uint4 nxt = cur;
+                if (p + 16 < main_end)
+                    nxt = *reinterpret_cast<const uint4 *>(wsrc + soff + p + 16);
+                encode_chunk<U16, FIXUP, false>(T, S, cur, p, nfreeze, rc, sh, wdst);
+                cur = nxt;
+            }
+        }
+    }
+
+    // Tail: symbol by symbol with per-lane predicates (ragged lengths, the EOF symbol).
+    for (; p <= maxlen; p++) {
+        const uint32_t nup = p < nfreeze ? p : nfreeze;
+        const double   r   = rc[nup];
+        const uint32_t c   = 257u + nup;
+        if (live && p < len) {
+            uint32_t lo, hi;
+            // The update of a block's last symbol is never observed (the EOF range is
+            // derived), and skipping it keeps every u16 node below 65536.
+            T.template get_frequency<true>(wsrc[soff + p], nup, p < nfreeze && p + 1 != len, lo, hi);
+            encode_symbol<FIXUP>(S, lo, hi, c, r, sh, false, wdst, limit);
+        } else if (live && p == len) {
+            // EOF symbol (codec.rs:108): cum(256) = count-1, cum(257) = count
+            const uint32_t shifts = encode_symbol<FIXUP>(S, c - 1, c, c, r, sh, true, wdst, limit);
+            const uint32_t size   = encode_finish(S, shifts, a.code_bits, off0, wdst, limit);
+            a.sizes[blk]  = size;
+            a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+        }
+    }
+}
+
+// ======================================================================================
+// encode, two waves per 64 blocks (the production path for u16 trees)
+//
+// The tree (32 KiB per 64 blocks) caps a CU at four groups of 64 blocks -- one wave per SIMD
+// if a group is one wave, and a lone wave issues one instruction per ~4 cycles.  The model
+// (tree query + update) does not depend on the coder's interval state, so a group is split
+// into a MODEL wave and a CODER wave that share the group's LDS:
+//   wave 0: input bytes -> get_frequency -> (low, high) pairs into an LDS ring
+//   wave 1: ring -> interval narrowing, renormalisation, bit output
+// Eight waves per CU = two per SIMD, so each SIMD always has a second instruction stream to
+// issue from.  (Measured, profiles/r01_ubench: a gfx950 SIMD retires the VOP3-type ops this
+// code is made of at ~4.5 cycles per wave-instruction however many waves feed it, so the two
+// streams together run at the SIMD's VALU rate.  Two three-wave variants were built, passed
+// the whole parity suite and were removed because they were slower: the model split by tree
+// level (+35 %: duplicated per-symbol work) and a three-stage pipeline nodes -> sums -> coder
+// with no duplicated work (+83 %: the LDS only has room for 2-symbol ring halves, and three
+// synchronised waves get LESS aggregate VALU throughput than two, 5.7 vs 4.9 cycles per
+// instruction in tools/ubench "40 VALU + barrier").)  The ring holds 2 x 8 symbols x 64 lanes x 8 B = 8 KiB (40 KiB per workgroup,
+// four workgroups = the CU's 160 KiB exactly); one s_barrier per 8 symbols hands a half over.
+// Only LDS traffic must be complete at the hand-off, so the barrier waits on lgkmcnt alone:
+// the coder's stores and the model's prefetch loads stay in flight across it.
+// ======================================================================================
+constexpr uint32_t kRingSlots = 8;                               // symbols per hand-off
+constexpr uint32_t kRingBytes = 2 * kRingSlots * 64 * 8;         // two halves of uint2[8][64]
+
+#ifdef REDUX_STAMPS
+// Diagnostic build only (never timed, never shipped): every ring barrier is bracketed by
+// s_memtime; lane 0 of each wave accumulates {last stamp, cycles between barriers, cycles
+// inside barriers, count} in the tree's unused row 0 (LDS bytes 0..63) and the kernel copies
+// them to the spare slot at exit.  The barrier drains lgkmcnt anyway, so the stamps do not
+// change what the waves overlap.
+typedef __attribute__((address_space(3))) unsigned long long *lds64p;
+__device__ __forceinline__ void pair_barrier()
+{
+    unsigned long long t0, t1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1)::"memory");
+    if ((threadIdx.x & 63) == 0) {
+        lds64p a = (lds64p)(uintptr_t)((threadIdx.x >> 6) * 32);
+        const unsigned long long prev = a[0];
+        if (prev)
+            a[1] += t0 - prev;
+        a[2] += t1 - t0;
+        a[0] = t1;
+        a[3] += 1;
+    }
+}
+#else
+__device__ __forceinline__ void pair_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+#endif
+
+// Input path of the model wave: every lane reads its own block one whole 128-byte line at a
+// time (eight 16-byte loads issued back to back), so each line crosses the L2 <-> fabric
+// boundary once: FETCH_SIZE 2.14e6 KiB per 4 GiB pass, identical to a clean streaming read,
+// against 7.4e6-9.5e6 KiB with 16 bytes per visit (the line was evicted between visits), and
+// WRITE_SIZE drops 38 % as well (less L2 pollution).  c[] is the current line, n[] the next
+// one, already in flight; the chunk index is wave-uniform (the lanes advance in lock-step),
+// so pop() is a scalar switch.  Costs 2.8 % of kernel time (profiles/r01_traffic_matrix.txt);
+// -DREDUX_NO_LINE_QUEUE restores the 16-byte prefetch for A/B runs.
+struct ChunkQueue {
+    const uint8_t *base; // wave-uniform
+    uint32_t       soff; // this lane's block offset
+    uint32_t       last; // offset of the last 16-byte chunk the unrolled path reads
+    uint32_t       nextp;
+    uint32_t       idx;  // next chunk of c[] (wave-uniform)
+    uint4          c[8], n[8];
+
+    // chunks past the end re-read the last valid chunk (never used)
+    __device__ __forceinline__ void prefetch()
+    {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t p = nextp + 16 * i;
+            n[i] = *reinterpret_cast<const uint4 *>(base + soff + (p < last ? p : last));
+        }
+        nextp += 128;
+    }
+    // current line <- prefetched line, then put the line after it in flight
+    __device__ __forceinline__ void swap()
+    {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            c[i] = n[i];
+        idx = 0;
+        prefetch();
+    }
+    __device__ __forceinline__ void init(const uint8_t *b, uint32_t so, uint32_t e)
+    {
+        base = b; soff = so; last = e - 16; nextp = 0;
+        prefetch();
+        swap();
+    }
+    // the next 16 bytes of every lane's block
+    __device__ __forceinline__ uint4 pop()
+    {
+        uint4 r;
+        switch (idx) {
+        case 0: r = c[0]; break;
+        case 1: r = c[1]; break;
+        case 2: r = c[2]; break;
+        case 3: r = c[3]; break;
+        case 4: r = c[4]; break;
+        case 5: r = c[5]; break;
+        case 6: r = c[6]; break;
+        default: r = c[7]; break;
+        }
+        if (++idx == 8)
+            swap();
+        return r;
+    }
+};
+
+#ifndef REDUX_KEEP8
+#define REDUX_KEEP8 1
+#endif
+#ifndef REDUX_MODEL_PRIO
+#define REDUX_MODEL_PRIO 3
+#endif
+#ifndef REDUX_ROWS // 1: the pair kernel writes ROW-major group areas (row r = dword r of the 64 lanes), k_compact_rows gathers them
+#define REDUX_ROWS 0
+#endif
+constexpr int kPairStride = REDUX_ROWS ? 256 : 4;
+#ifndef REDUX_MODEL_DEPTH
+#define REDUX_MODEL_DEPTH 1
+#endif
+template <bool UPD>
+__device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, uint32_t lane, const uint4 cur,
+                                            uint32_t p, uint32_t nfreeze)
+{
+    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+    auto sym = [&](int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; };
+    // software pipeline: symbol i+1's LDS ops are in flight while symbol i's sums are formed
+    // (depths 2 and 3 measured no faster: the wave is bound by its own issue rate, not by LDS)
+    constexpr int D = REDUX_MODEL_DEPTH;
+    Tree<true>::Nodes q[D + 1];
+#pragma unroll
+    for (int d = 0; d < D; d++)
+        q[d] = T.template issue<UPD>(sym(d), true);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t s   = sym(i);
+        const uint32_t nup = UPD ? p + i : nfreeze;
+        // At the hand-over in the middle of the chunk the next symbol's eight LDS ops are issued
+        // AFTER this symbol's ring write and stay in flight across the barrier (LDS ops of a wave
+        // complete in order, so lgkmcnt <= 8 means the ring half is written).
+        const bool late = REDUX_KEEP8 && i == 7;
+        if (i + D < 16 && !late) {
+            q[D] = T.template issue<UPD>(sym(i + D), true);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t lo, hi;
+        T.finish(s, nup, q[0], lo, hi);
+        ring[i * 64 + lane] = make_uint2(lo, hi);
+        if (late) {
+            __builtin_amdgcn_sched_barrier(0);
+            q[D] = T.template issue<UPD>(sym(i + D), true);
+            asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+        } else if ((i & 7) == 7)
+            pair_barrier();
+#pragma unroll
+        for (int d = 0; d < D; d++)
+            q[d] = q[d + 1];
+    }
+}
+
+// MODE 0: adaptive chunk (reciprocals rc[p..p+15]); MODE 1: frozen chunk (rc[nfreeze]).
+// MODE 0 takes the reciprocals of its first eight symbols in r[] and leaves those of the next
+// chunk's first eight there: each half loads the following half's eight right after its own
+// ring reads have arrived, at the start of an eight-symbol stretch with no lgkmcnt wait in it.
+// (SMEM shares lgkmcnt with LDS and returns out of order, so any LDS wait or ring barrier also
+// waits for every scalar load in flight; loaded at the top of the chunk, their miss latency sat
+// in front of the first barrier.  Sixteen at a time would need 64 SGPRs: spills.)
+template <bool FIXUP, int MODE, bool CB32>
+__device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint32_t lane, uint32_t p,
+                                            uint32_t nfreeze, rc_ptr rc, uint32_t sh, uint8_t *wdst, double (&r)[8])
+{
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        pair_barrier();
+        uint2 lh[8]; // the whole half at once: one LDS round trip per 8 symbols
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            lh[i] = ring[(h * 8 + i) * 64 + lane];
+        double rn[8];
+        if (MODE == 0) {
+            uint32_t zero; // opaque 0 that "depends" on the ring data: pins the loads behind the LDS wait
+            asm volatile("s_mov_b32 %0, 0" : "=s"(zero) : "v"(lh[0].x));
+            const rc_ptr nb = rc + (p + 8u * h + 8u + zero); // the table has 32 entries of slack (geometry())
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                rn[i] = nb[i];
+        }
+#ifdef REDUX_CODER_BRANCHY // the older form: a ballot branch inside every symbol
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
+            uint32_t       hi  = lh[i].y;
+            asm volatile("" : "+v"(hi)); // keeps ISel from turning (u64 >> 32) -> f64 into a 64-bit conversion (+1 v_add_f64)
+            encode_symbol_fast<FIXUP, CB32>(S, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
+        }
+#else
+        // Eight symbols straight-line; the rare symbol whose pending run needs more than one
+        // 32-bit append only raises a flag, and the half is then redone from the saved state
+        // with the general encode_symbol (no per-symbol branch, no merge of two state versions).
+        const EncState S0 = S;
+        uint64_t       bad = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
+            uint32_t       hi  = lh[i].y;
+            // keeps ISel from turning (u64 >> 32) -> f64 into a 64-bit conversion (+1 v_add_f64); converting
+            // as signed avoids that too, but v_cvt_f64_i32 measured 9 % slower for the whole kernel
+            asm volatile("" : "+v"(hi));
+            bad |= encode_symbol_spec<FIXUP, CB32, kPairStride>(S, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
+        }
+        if (__builtin_expect(bad != 0, 0)) {
+            S = S0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
+                encode_symbol<FIXUP, kPairStride>(S, lh[i].x, lh[i].y, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, false, wdst, 0xFFFFFFFFu);
+            }
+        }
+#endif
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                r[i] = rn[i];
+        }
+    }
+}
+
+// any chunk, rolled, every store checked against the slot limit
+template <bool FIXUP>
+__device__ __forceinline__ void coder_chunk_checked(EncState &S, const uint2 *ring, uint32_t lane, uint32_t p,
+                                                    uint32_t nfreeze, rc_ptr rc, uint32_t sh, uint8_t *wdst,
+                                                    uint32_t limit)
+{
+    for (uint32_t i = 0; i < 16; i++) {
+        if ((i & 7) == 0)
+            pair_barrier();
+        const uint2    lh  = ring[i * 64 + lane];
+        const uint32_t q   = p + i;
+        const uint32_t nup = q < nfreeze ? q : nfreeze;
+        encode_symbol<FIXUP, kPairStride>(S, lh.x, lh.y, 257u + nup, rc[nup], sh, false, wdst, limit);
+    }
+}
+
+// The pair kernel needs every SIMD to hold exactly ONE model wave and ONE coder wave.  Where the
+// two waves of a 128-thread workgroup land is up to the dispatcher: launched on an idle chip it
+// alternates them perfectly, launched right after another kernel it puts two first-waves on
+// some SIMDs (profiles/r01_final/placement_census.txt) -- two model waves at half speed each,
+// which the whole lock-step kernel then waits for (0.5-3 ms of 13).  So the roles are not tied
+// to the wave index: they are booked per CU at run time (REDUX_CLAIMS, below).
+// (Tried instead: whole-CU workgroups of eight waves = four pairs, waves w and w+4 sharing a
+// SIMD.  Placement is then perfect by construction, but the eight-wave s_barrier couples the
+// four pairs and the kernel takes 14.05 ms against 12.8 ms.)
+#ifndef REDUX_CLAIMS
+#define REDUX_CLAIMS 1
+#endif
+constexpr uint32_t kClaimWords = 2048; // (xcc:3, se:3, sh:1, cu:4) -> one word per CU
+constexpr uint32_t kPairDwords = Tree<true>::kDwords + kRingBytes / 4;
+
+template <bool FIXUP, bool CB32>
+__global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
+{
+    __shared__ uint32_t lds[kPairDwords];
+    const uint32_t w8   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // first or second wave of the workgroup
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t blk0 = (uint64_t)blockIdx.x * a.lanes;
+    const uint64_t blk  = blk0 + lane;
+    const bool     live = lane < a.lanes && blk < a.nblocks;
+
+    for (uint32_t i = threadIdx.x; i < Tree<true>::kDwords / 4; i += 128)
+        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    uint32_t role = w8;
+    uint2   *ring = reinterpret_cast<uint2 *>(lds + Tree<true>::kDwords);
+#if REDUX_CLAIMS
+    // claims[cu] counts the model waves (bits 4s..4s+3) and coder waves (bits 16+4s..) booked on
+    // SIMD s of that CU.  A workgroup whose waves sit on SIMDs (s0, s1) books (model, coder) =
+    // (s0, s1), or (s1, s0) when that collides with fewer roles already booked, and returns its
+    // booking when its coder wave ends.  Greedy, so not always perfect, but on an idle chip the
+    // dispatcher's own choice is kept and after a compaction every SIMD still gets (1, 1).
+    uint32_t claim_delta = 0; // (a VGPR on purpose: it is live across the whole kernel)
+    {
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        // (the last 16 bytes of the ring: the model wave writes there only after the first hand-off)
+        volatile uint32_t *book = reinterpret_cast<volatile uint32_t *>(ring) + kRingBytes / 4 - 4;
+        if (lane == 0)
+            book[w8] = (hwid >> 4) & 3u; // my SIMD
+        __syncthreads();
+        uint32_t *claim_word = a.claims + (((xcc & 7u) << 8) | ((hwid >> 8) & 0xFFu)); // (xcc, se, sh, cu)
+        if (w8 == 0 && lane == 0) {
+            const uint32_t s0 = book[0], s1 = book[1];
+            const uint32_t straight = (1u << (4 * s0)) | (1u << (16 + 4 * s1));
+            const uint32_t flipped  = (1u << (4 * s1)) | (1u << (16 + 4 * s0));
+            uint32_t       old      = __hip_atomic_load(claim_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t       flip;
+            do {
+                const uint32_t cs = ((old >> (4 * s0)) & 15u) + ((old >> (16 + 4 * s1)) & 15u);
+                const uint32_t cf = ((old >> (4 * s1)) & 15u) + ((old >> (16 + 4 * s0)) & 15u);
+                flip              = cf < cs;
+            } while (!__hip_atomic_compare_exchange_strong(claim_word, &old, old + (flip ? flipped : straight),
+                                                           __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            book[2] = flip;
+            book[3] = flip ? flipped : straight;
+        }
+        __syncthreads();
+        role ^= __builtin_amdgcn_readfirstlane(book[2]);
+        claim_delta = book[3];
+    }
+#else
+    __syncthreads();
+#endif
+    const uint32_t wave = role; // 0 = model, 1 = coder
+    Tree<true> T;
+    T.init(lds, lane);
+
+    uint32_t len = 0;
+    if (live) {
+        const uint64_t rem = a.in_len - blk * a.block_size;
+        len                = rem < a.block_size ? (uint32_t)rem : a.block_size;
+    }
+    const uint8_t *wsrc  = a.in + blk0 * a.block_size;
+    const uint32_t soff  = live ? lane * a.block_size : 0u;
+#if REDUX_ROWS
+    // row-major group area: dword r of lane l at wdst + 256 r + 4 l (dead lanes own a column too).
+    // The areas are an ODD number of 128-byte lines apart: all groups write row r at about the
+    // same time, and an even stride folds those lines onto a fraction of the L2 sets.
+    uint8_t       *wdst  = a.slots + (uint64_t)blockIdx.x * (64 * a.slot_bytes + 128);
+    const uint32_t off0  = lane * 4u;
+    const uint32_t limit = off0 + (a.slot_cap / 4u) * 256u;
+#else
+    uint8_t       *wdst  = a.slots + blk0 * a.slot_bytes;
+    const uint32_t off0  = live ? lane * (uint32_t)a.slot_bytes : (uint32_t)(a.nblocks - blk0) * (uint32_t)a.slot_bytes;
+    const uint32_t limit = off0 + a.slot_cap;
+#endif
+
+    const uint32_t minlen  = __builtin_amdgcn_readfirstlane(wave_min(live ? len : 0xFFFFFFFFu));
+    const uint32_t maxlen  = __builtin_amdgcn_readfirstlane(wave_max(live ? len : 0u));
+    const uint32_t sh      = 32 - a.code_bits;
+    const uint32_t nfreeze = a.nfreeze;
+    const rc_ptr   rc      = (rc_ptr)a.rc;
+    constexpr uint32_t kChunkBudget = (16 * 4 + 32) * (kPairStride / 4);
+
+    // both waves derive the same chunk schedule from wave-uniform values
+    uint32_t main_end = 0;
+    if (a.aligned16 && minlen != 0xFFFFFFFFu && minlen > 16)
+        main_end = (minlen - 1) & ~15u;
+    const uint32_t a_end = main_end < (nfreeze & ~15u) ? main_end : (nfreeze & ~15u); // adaptive chunks
+    const uint32_t m_end = (a_end < main_end && a_end < nfreeze) ? a_end + 16 : a_end; // freeze-crossing chunk
+
+    EncState S;
+    enc_init(S, off0);
+
+    if (wave == 0) {
+        // ---------------- model wave ----------------
+        // The model wave is the pair's critical path (it works ~590 cycles per symbol, the coder wave
+        // ~430 and then waits at the ring barrier), but the SIMD's arbiter serves the two waves
+        // round-robin: raising the model wave's issue priority lets it run at nearly the lone-wave
+        // rate while the coder wave fills the gaps.  15.96 -> 14.0 ms (REDUX_MODEL_PRIO=0 for the A/B).
+        __builtin_amdgcn_s_setprio(REDUX_MODEL_PRIO);
+        if (main_end) {
+            uint32_t p = 0;
+#ifndef REDUX_NO_LINE_QUEUE
+            ChunkQueue Q;
+            Q.init(wsrc, soff, main_end);
+#define NEXT_CHUNK() Q.pop()
+#else
+            uint4 cur = *reinterpret_cast<const uint4 *>(wsrc + soff);
+            auto  next_chunk = [&](uint32_t pp) {
+                const uint4 r = cur;
+                if (pp + 16 < main_end)
+                    cur = *reinterpret_cast<const uint4 *>(wsrc + soff + pp + 16);
+                return r;
+            };
+#define NEXT_CHUNK() next_chunk(p)
+#endif
+            for (; p < a_end; p += 16)
+                model_chunk<true>(T, ring, lane, NEXT_CHUNK(), p, nfreeze);
+            for (; p < m_end; p += 16) { // rolled: the update stops in the middle of this chunk
+                (void)NEXT_CHUNK();
+                for (uint32_t i = 0; i < 16; i++) {
+                    const uint32_t q   = p + i;
+                    const uint32_t nup = q < nfreeze ? q : nfreeze;
+                    uint32_t       lo, hi;
+                    T.template get_frequency<true>(wsrc[soff + q], nup, q < nfreeze, lo, hi);
+                    ring[i * 64 + lane] = make_uint2(lo, hi);
+                    if ((i & 7) == 7)
+                        pair_barrier();
+                }
+            }
+            for (; p < main_end; p += 16)
+                model_chunk<false>(T, ring, lane, NEXT_CHUNK(), p, nfreeze);
+#undef NEXT_CHUNK
+        }
+    } else {
+        // ---------------- coder wave ----------------
+#ifdef REDUX_CODER_PRIO
+        __builtin_amdgcn_s_setprio(REDUX_CODER_PRIO);
+#endif
+        uint32_t p = 0;
+        double   r[8];      // reciprocals of the first eight symbols of chunk r_at
+        uint32_t r_at = ~0u;
+        for (; p < main_end; p += 16) {
+            if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit) || (p >= a_end && p < m_end))
+                coder_chunk_checked<FIXUP>(S, ring, lane, p, nfreeze, rc, sh, wdst, limit);
+            else if (p < a_end) {
+                if (r_at != p) { // first chunk, or the previous one took the checked path
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        r[i] = rc[p + i];
+                }
+                coder_chunk<FIXUP, 0, CB32>(S, ring, lane, p, nfreeze, rc, sh, wdst, r);
+                r_at = p + 16;
+            } else
+                coder_chunk<FIXUP, 1, CB32>(S, ring, lane, p, nfreeze, rc, sh, wdst, r);
+        }
+    }
+    __syncthreads(); // the model wave's last updates are in LDS before the tail reads the tree
+#ifdef REDUX_STAMPS
+    if (lane == 0) {
+        lds64p st = (lds64p)(uintptr_t)(w8 * 32);
+        unsigned long long *dstp = reinterpret_cast<unsigned long long *>(a.slots + a.nblocks * a.slot_bytes) + (blockIdx.x * 2 + wave) * 4;
+        uint32_t hwid, xcc; // where this wave ran: (xcc, se, sh, cu, simd) -- the pair needs one model and one coder wave per SIMD
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dstp[0] = st[1]; dstp[1] = st[2]; dstp[2] = st[3];
+        dstp[3] = wave | ((unsigned long long)(hwid & 0xFFFFu) << 8) | ((unsigned long long)(xcc & 0xFu) << 24);
+    }
+#endif
+    if (wave == 0)
+        return;
+
+    // Tail (coder wave only): symbol by symbol with per-lane predicates.
+    for (uint32_t p = main_end; p <= maxlen; p++) {
+        const uint32_t nup = p < nfreeze ? p : nfreeze;
+        const double   r   = rc[nup];
+        const uint32_t c   = 257u + nup;
+        if (live && p < len) {
+            uint32_t lo, hi;
+            T.template get_frequency<true>(wsrc[soff + p], nup, p < nfreeze && p + 1 != len, lo, hi);
+            encode_symbol<FIXUP, kPairStride>(S, lo, hi, c, r, sh, false, wdst, limit);
+        } else if (live && p == len) {
+            const uint32_t shifts = encode_symbol<FIXUP, kPairStride>(S, c - 1, c, c, r, sh, true, wdst, limit);
+            const uint32_t size   = encode_finish<kPairStride>(S, shifts, a.code_bits, off0, wdst, limit);
+            a.sizes[blk]  = size;
+            a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+        }
+    }
+#if REDUX_CLAIMS
+    if (lane == 0) { // waves do not migrate: the same CU as at the start
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_fetch_sub(a.claims + (((xcc & 7u) << 8) | ((hwid >> 8) & 0xFFu)), claim_delta, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
+}
+
+} // namespace redux

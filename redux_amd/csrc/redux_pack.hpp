@@ -1,0 +1,320 @@
+// redux_pack.hpp -- what turns per-block slots into the dense stream (gfx950 only).
+//
+//   k_summarize      first failing status + number of failing blocks
+//   k_scan_sizes     sizes -> offsets (exclusive scan, one workgroup) + status summary
+//   k_compact        slot b [0, size_b) -> out + offsets[b], 16-byte stores with byte realignment
+//   k_compact_rows   the same from row-major group areas (-DREDUX_ROWS=1 builds)
+//
+// Included by redux_hip.hip (one translation unit).
+#pragma once
+
+#include "redux_coder.hpp"
+#include "redux_encode.hpp" // REDUX_ROWS
+
+#include "../../include/redux_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace redux {
+
+__global__ void k_summarize(const int32_t *status, uint64_t nblocks, int32_t *summary)
+{
+    uint32_t bad = 0;
+    uint64_t first = ~0ull;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += (uint64_t)gridDim.x * blockDim.x)
+        if (status[b] != REDUX_OK) {
+            bad++;
+            if (first == ~0ull)
+                first = b;
+        }
+    if (bad) {
+        atomicAdd(&summary[1], (int32_t)bad);
+        atomicCAS(&summary[0], REDUX_OK, status[first]);
+    }
+}
+
+// ======================================================================================
+// sizes -> offsets, status summary
+// ======================================================================================
+struct ScanArgs {
+    const uint32_t *sizes;
+    const int32_t  *status;
+    uint64_t       *offsets; // nblocks + 1
+    int32_t        *summary; // may be null: [first bad status, #bad]
+    uint64_t        nblocks;
+};
+
+__global__ void __launch_bounds__(1024) k_scan_sizes(ScanArgs a)
+{
+    __shared__ uint64_t part[1024];
+    __shared__ uint32_t bad_cnt;
+    __shared__ uint64_t bad_first; // (index << 8) | status, minimised
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        bad_cnt   = 0;
+        bad_first = ~0ull;
+    }
+    const uint64_t per = (a.nblocks + 1023) / 1024;
+    const uint64_t b0  = per * tid < a.nblocks ? per * tid : a.nblocks;
+    const uint64_t b1  = b0 + per < a.nblocks ? b0 + per : a.nblocks;
+    uint64_t       sum = 0;
+    uint32_t       nb  = 0;
+    uint64_t       fb  = ~0ull;
+    // Up to 64 blocks per thread in whole quads (the 65,536-block configuration): the sizes stay
+    // in registers between the two passes and move as 16-byte loads, all in flight at once,
+    // instead of 3 x 64 dependent 4-byte accesses per thread.
+    const bool quads = per <= 64 && (per & 3) == 0 && (a.nblocks % per) == 0 &&
+                       ((((uintptr_t)a.sizes) | ((uintptr_t)a.status) | ((uintptr_t)a.offsets)) & 15) == 0;
+    uint4      sz[16];
+    if (quads) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(a.sizes + b0);
+        const int4  *t4 = reinterpret_cast<const int4 *>(a.status + b0);
+        int4         stv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool in = b0 + 4 * i < b1;
+            sz[i]  = in ? s4[i] : make_uint4(0, 0, 0, 0);
+            stv[i] = in ? t4[i] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            sum += (uint64_t)sz[i].x + sz[i].y + sz[i].z + sz[i].w;
+            const int32_t st4[4] = {stv[i].x, stv[i].y, stv[i].z, stv[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (st4[k] != REDUX_OK) {
+                    nb++;
+                    if (fb == ~0ull)
+                        fb = ((b0 + 4 * i + k) << 8) | (uint32_t)st4[k];
+                }
+        }
+    } else {
+        for (uint64_t b = b0; b < b1; b++) {
+            sum += a.sizes[b];
+            const int32_t st = a.status[b];
+            if (st != REDUX_OK) {
+                nb++;
+                if (fb == ~0ull)
+                    fb = (b << 8) | (uint32_t)st;
+            }
+        }
+    }
+    part[tid] = sum;
+    __syncthreads();
+    if (nb) {
+        atomicAdd(&bad_cnt, nb);
+        atomicMin((unsigned long long *)&bad_first, (unsigned long long)fb);
+    }
+    // Hillis-Steele inclusive scan over the 1024 partials
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint64_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint64_t run = tid ? part[tid - 1] : 0;
+    if (quads) {
+        ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(a.offsets + b0); // b0 is a multiple of 4: 16-byte aligned
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (b0 + 4 * i < b1) {
+                const uint64_t r1 = run + sz[i].x, r2 = r1 + sz[i].y, r3 = r2 + sz[i].z;
+                o2[2 * i]     = make_ulonglong2(run, r1);
+                o2[2 * i + 1] = make_ulonglong2(r2, r3);
+                run           = r3 + sz[i].w;
+            }
+    } else {
+        for (uint64_t b = b0; b < b1; b++) {
+            a.offsets[b] = run;
+            run += a.sizes[b];
+        }
+    }
+    if (tid == 1023)
+        a.offsets[a.nblocks] = part[1023];
+    if (tid == 0 && a.summary) {
+        a.summary[0] = bad_cnt ? (int32_t)(bad_first & 0xFF) : REDUX_OK;
+        a.summary[1] = (int32_t)bad_cnt;
+    }
+}
+
+// ======================================================================================
+// compaction: slot b [0, size_b) -> out + offsets[b]
+// ======================================================================================
+struct CompactArgs {
+    const uint8_t  *slots;
+    uint64_t        slot_bytes;
+    const uint64_t *offsets;
+    uint8_t        *out;
+    uint64_t        out_cap;
+    int32_t        *status;
+    int32_t        *summary;
+    uint64_t        nblocks;
+    const uint32_t *mode;     // 0: linear slots (k_compact), != 0: row-major group areas (k_compact_rows)
+    uint32_t        cap_rows; // rows of a group area
+};
+
+__global__ void __launch_bounds__(256) k_compact(CompactArgs a)
+{
+    const uint64_t b = blockIdx.x;
+    if (b >= a.nblocks || *a.mode != 0)
+        return;
+    const uint64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
+    const uint32_t tid = threadIdx.x;
+    if (o1 > a.out_cap) { // the dense buffer is too small for this block: report, never write
+        if (tid == 0) {
+            if (a.status[b] == REDUX_OK)
+                a.status[b] = REDUX_OUTPUT_TOO_SMALL;
+            if (a.summary) {
+                atomicCAS(&a.summary[0], REDUX_OK, REDUX_OUTPUT_TOO_SMALL);
+                atomicAdd(&a.summary[1], 1);
+            }
+        }
+        return;
+    }
+    const uint32_t n   = (uint32_t)(o1 - o0);
+    const uint8_t *src = a.slots + b * a.slot_bytes; // 16-byte aligned
+    uint8_t       *dst = a.out + o0;
+
+    // head: bytes up to the first 16-byte boundary of dst
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (head > n)
+        head = n;
+    if (tid < head)
+        dst[tid] = src[tid];
+    // body: 16-byte dst chunks; the source is misaligned by the uniform amount `head`
+    const uint32_t nchunks = (n - head) >> 4;
+    const uint32_t dq = head >> 2, r = head & 3;
+    const uint4   *s16 = reinterpret_cast<const uint4 *>(src);
+    uint4         *d16 = reinterpret_cast<uint4 *>(dst + head);
+    for (uint32_t i = tid; i < nchunks; i += 256) {
+        const uint4    A = s16[i], B = s16[i + 1]; // slot padding keeps i+1 inside the slot
+        const uint32_t d[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
+        uint32_t       v[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            v[k] = dq == 0 ? d[k] : dq == 1 ? d[k + 1] : dq == 2 ? d[k + 2] : d[k + 3];
+        uint4 o;
+        o.x = __builtin_amdgcn_alignbyte(v[1], v[0], r);
+        o.y = __builtin_amdgcn_alignbyte(v[2], v[1], r);
+        o.z = __builtin_amdgcn_alignbyte(v[3], v[2], r);
+        o.w = __builtin_amdgcn_alignbyte(v[4], v[3], r);
+        d16[i] = o;
+    }
+    // tail
+    const uint32_t done = head + (nchunks << 4);
+    if (tid < n - done)
+        dst[done + tid] = src[done + tid];
+}
+
+// Row-major group areas (REDUX_ROWS): row r of group g holds dword r of its 64 streams
+// (slots + g * 64 * slot_bytes + 256 r + 4 l).  One workgroup gathers a tile of 64 rows: the
+// rows are read whole (coalesced) into LDS, then every stream's 64 dwords of the tile leave as
+// one 256-byte run of ALIGNED dwords of the dense output: output dword j of a stream that starts
+// at byte offset sh (0..3) inside its first aligned dword is the byte-funnel of source dwords
+// j-1 and j.  Only a stream's first and last output dword can be partial: those go bytewise.
+constexpr uint32_t kTileRows = 64;
+__global__ void __launch_bounds__(256) k_compact_rows(CompactArgs a)
+{
+    if (*a.mode == 0)
+        return;
+    __shared__ uint32_t tile[(kTileRows + 1) * 65]; // +1 leading row (source dword j-1); pitch 65: conflict-free column reads
+    __shared__ uint64_t s_dst[64];                  // aligned dword that holds each stream's first byte (0: skip the stream)
+    __shared__ uint32_t s_n[64], s_sh[64];
+    __shared__ uint32_t s_maxj;
+    const uint32_t tiles = (a.cap_rows + kTileRows - 1) / kTileRows + 1;
+    const uint64_t g     = blockIdx.x / tiles;
+    const uint32_t r0    = (blockIdx.x % tiles) * kTileRows;
+    const uint32_t tid   = threadIdx.x;
+    if (tid == 0)
+        s_maxj = 0;
+    __syncthreads();
+    if (tid < 64) { // where does each stream go, and how many output dwords does the longest one need?
+        const uint64_t b = g * 64 + tid;
+        uint64_t       d = 0;
+        uint32_t       n = 0, sh = 0;
+        if (b < a.nblocks) {
+            const uint64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
+            if (o1 <= a.out_cap) {
+                n  = (uint32_t)(o1 - o0);
+                sh = (uint32_t)((uintptr_t)(a.out + o0) & 3);
+                d  = (uint64_t)(uintptr_t)(a.out + o0) - sh;
+                atomicMax(&s_maxj, (sh + n + 3) >> 2);
+            } else if (r0 == 0) { // the dense buffer is too small for this block: report, never write
+                if (a.status[b] == REDUX_OK)
+                    a.status[b] = REDUX_OUTPUT_TOO_SMALL;
+                if (a.summary) {
+                    atomicCAS(&a.summary[0], REDUX_OK, REDUX_OUTPUT_TOO_SMALL);
+                    atomicAdd(&a.summary[1], 1);
+                }
+            }
+        }
+        s_dst[tid] = d;
+        s_n[tid]   = n;
+        s_sh[tid]  = sh;
+    }
+    __syncthreads();
+    if (r0 >= s_maxj)
+        return;
+    const uint4 *area = reinterpret_cast<const uint4 *>(a.slots + g * (64 * a.slot_bytes + 128));
+    // tile row i (0..64) = source row r0 - 1 + i; a row is 16 uint4.  All loads first, then the LDS writes.
+    uint4 v[4], lead = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t e = tid + 256 * q, r = r0 + (e >> 4);
+        v[q] = r < a.cap_rows ? area[(uint64_t)r * 16 + (e & 15)] : make_uint4(0, 0, 0, 0);
+    }
+    if (tid < 16 && r0 > 0)
+        lead = area[(uint64_t)(r0 - 1) * 16 + tid];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t e = tid + 256 * q;
+        uint32_t      *w = &tile[((e >> 4) + 1) * 65 + (e & 15) * 4];
+        w[0] = v[q].x; w[1] = v[q].y; w[2] = v[q].z; w[3] = v[q].w;
+    }
+    if (tid < 16) {
+        uint32_t *w = &tile[tid * 4];
+        w[0] = lead.x; w[1] = lead.y; w[2] = lead.z; w[3] = lead.w;
+    }
+    __syncthreads();
+    // thread -> (stream, four consecutive output dwords): one 16-byte store where the whole quad is inside the stream
+    const uint32_t wave = tid >> 6, t = tid & 63;
+#pragma unroll 2
+    for (uint32_t it = 0; it < 4; it++) {
+        const uint32_t l  = wave * 16 + it * 4 + (t >> 4);
+        const uint32_t jq = (t & 15) * 4; // tile-relative first output dword
+        const uint64_t d  = s_dst[l];
+        const uint32_t n = s_n[l], sh = s_sh[l];
+        const uint32_t j0 = r0 + jq;
+        if (d == 0 || j0 >= ((sh + n + 3) >> 2))
+            continue;
+        uint32_t src[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            src[c] = tile[(jq + c) * 65 + l]; // source dwords j0-1 .. j0+3
+        uint32_t w[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            w[c] = sh ? __builtin_amdgcn_alignbyte(src[c + 1], src[c], 4 - sh) : src[c + 1];
+        uint8_t      *A     = reinterpret_cast<uint8_t *>((uintptr_t)d) + 4 * (uint64_t)j0;
+        const int64_t first = (int64_t)4 * j0 - sh; // stream index of the quad's byte 0
+        if (first >= 0 && first + 16 <= (int64_t)n) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+            *reinterpret_cast<u32x4 *>(A) = u32x4{w[0], w[1], w[2], w[3]};
+        } else { // a stream's head or tail: dwords where whole, bytes where not
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int64_t f = first + 4 * c;
+                if (f >= 0 && f + 4 <= (int64_t)n) {
+                    *reinterpret_cast<uint32_t *>(A + 4 * c) = w[c];
+                } else {
+                    for (int i = 0; i < 4; i++)
+                        if (f + i >= 0 && f + i < (int64_t)n)
+                            A[4 * c + i] = (uint8_t)(w[c] >> (8 * i));
+                }
+            }
+        }
+    }
+}
+
+} // namespace redux
