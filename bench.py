@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the decode measurement / round-trip check")
     ap.add_argument("--cpu-sample-blocks", type=int, default=4096)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: usable cores)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="all ranks share cuda:0 and rendezvous over gloo: exercises the multi-rank code path on a one-GPU box "
+                         "(the line says so; not a scaling measurement)")
     args = ap.parse_args()
 
     import torch
@@ -78,9 +81,13 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    if world > 1 and args.rehearse_on_one_gpu:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     import redux_amd as rx
@@ -180,6 +187,8 @@ def main():
         },
     }
 
+    if args.rehearse_on_one_gpu:
+        line["rehearsal"] = f"{world} ranks shared cuda:0 over gloo: a code-path check, not a scaling measurement"
     if not args.no_decode:
         dec = rx.DeviceDecoder(PARAMS, BLOCK, nblocks, device=dev)
         offs_t = enc.offsets[: nblocks + 1]
