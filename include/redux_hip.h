@@ -137,6 +137,13 @@ const char *redux_version(void);
  * and relies on this error staying below 2^-24 over that whole range. */
 int redux_debug_rcp_check(uint64_t lo, uint64_t hi, double *max_err);
 
+/* Diagnostic, used by the parity tests only: byte offset and length, inside the encode workspace
+ * of (p, in_len, block_size), of the encoder's per-CU role book (see redux_encode.hpp).  Every
+ * encode workgroup returns its booking when it ends, so the region reads all-zero after a
+ * completed redux_encode_slots_dev / redux_encode_blocks_dev. */
+int redux_debug_role_book(const redux_params *p, uint64_t in_len, uint32_t block_size, uint64_t *offset,
+                          uint64_t *bytes);
+
 #ifdef __cplusplus
 }
 #endif

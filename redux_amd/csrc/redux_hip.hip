@@ -538,6 +538,20 @@ extern "C" int redux_debug_dec_stamps(uint64_t *out8)
 }
 #endif
 
+// Diagnostic (tests only): where the encoder's per-CU role book sits in the workspace.
+int redux_debug_role_book(const redux_params *p, uint64_t in_len, uint32_t block_size, uint64_t *offset, uint64_t *bytes)
+{
+    int st = check_params(p);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0 || !offset || !bytes)
+        return REDUX_INVALID_INPUT;
+    const Geometry g = geometry(p, in_len, block_size);
+    *offset          = g.off_mode + 256;
+    *bytes           = kClaimWords * 4;
+    return REDUX_OK;
+}
+
 // Diagnostic (tests only): max |v_rcp_f64(x) * x - 1| over the integers lo..hi, on the device.
 int redux_debug_rcp_check(uint64_t lo, uint64_t hi, double *max_err)
 {

@@ -359,6 +359,38 @@ def test_device_resident_pipeline(rx, kind, nblocks):
     assert torch.equal(d_out, d_in)
 
 
+@pytest.mark.parametrize("nblocks", [1, 64 * 37 + 5, 64 * 1024 + 64 * 300 + 1])
+def test_encoder_role_book_is_returned(rx, nblocks):
+    """k_encode_pair books its (model, coder) roles per CU in the workspace and returns the
+    booking when the workgroup ends: after any completed encode -- fewer workgroups than the
+    chip holds, a partial last group, more than one resident round -- the book reads zero, and
+    a second encode on the same workspace produces the same bytes."""
+    import ctypes as C
+    import torch
+    from redux_amd import _lib
+    bs = 4096  # small blocks keep the largest case at 350 MB
+    n = nblocks * bs - 7
+    d_in = rx.gen_zipf(n)
+    enc = rx.DeviceEncoder((8, 30, 32), bs, n)
+    off, nbytes = C.c_uint64(), C.c_uint64()
+    assert _lib.lib().redux_debug_role_book(C.byref(enc.cp), n, bs, C.byref(off), C.byref(nbytes)) == 0
+    assert nbytes.value == 8192
+    firsts = []
+    for _ in range(2):
+        out, offs, status, summary = enc.encode(d_in)
+        torch.cuda.synchronize()
+        assert summary.tolist() == [0, 0]
+        book = enc.ws[enc.ws_off + off.value: enc.ws_off + off.value + nbytes.value]
+        assert int(book.count_nonzero()) == 0
+        firsts.append(out[: int(offs[nblocks])].clone())
+    assert torch.equal(firsts[0], firsts[1])
+    host = d_in.cpu().numpy()
+    offs_h = offs.cpu().numpy()
+    for b in sorted({0, nblocks // 2, nblocks - 1}):
+        want, _ = ox.compress(host[b * bs:(b + 1) * bs].tobytes(), (8, 30, 32))
+        assert firsts[1][int(offs_h[b]): int(offs_h[b + 1])].cpu().numpy().tobytes() == want, b
+
+
 def test_dense_output_too_small_is_reported_not_overrun(rx):
     import ctypes as C
     import torch
