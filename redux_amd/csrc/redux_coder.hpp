@@ -99,11 +99,6 @@ struct Tree {
         return __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + byte_addr), v,
                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // node address for level b of symbol s: one v_and_or_b32 (level 7 is always node 128: none)
-    __device__ __forceinline__ uint32_t addr(uint32_t ss, int b) const
-    {
-        return b == 7 ? A[7] : ((ss & (((0xFFu << b) & 0xFFu) << kShift)) | A[b]);
-    }
     // this lane's value of the node at byte_addr (decode descent)
     __device__ __forceinline__ uint32_t node(uint32_t byte_addr) const
     {
@@ -119,19 +114,45 @@ struct Tree {
     // (and without the 2 wait states between a VALU VCC write and its VALU read).
     // Splitting issue() from finish() lets the caller put the next symbol's LDS traffic in
     // flight before it consumes this symbol's values.
-    template <bool UPD>
-    __device__ __forceinline__ Nodes issue(uint32_t s, bool upd) const
+    // issue() = fire(prep()).  prep() is the part that needs nothing but the symbol -- its row | this
+    // lane's column, and its inverted bits in this lane's slot -- so a caller can compute it early.
+    struct Prep {
+        uint32_t t, nsl;
+    };
+    __device__ __forceinline__ Prep prep(uint32_t s) const
     {
-        const uint32_t ss  = s << kShift;
-        const uint32_t nsl = (s << hsh) ^ nmask; // (~s & 0xFF) << hsh with s already extracted: shift + xor
-        const uint32_t iv  = upd ? inc : 0u;
+        Prep r;
+        r.t = (s << kShift) | L;
+        asm volatile("" : "+v"(r.t)); // opaque: otherwise (ss | L) & keep is distributed back into one VOP3 per level
+        r.nsl = (s << hsh) ^ nmask;   // (~s & 0xFF) << hsh with s already extracted: shift + xor
+        return r;
+    }
+    // Level b keeps the bits of s above b and the column with ONE v_and, and the level's own bit
+    // -- a constant, known clear in the masked value -- rides in the DS instruction's offset field.
+    // top != nullptr: node 128 (level 7, the same node for every symbol) is kept in the caller's
+    // register instead of LDS -- one atomic fewer per symbol; the caller adds it back into LDS
+    // (add(A[7], *top)) before anything reads the tree from there.
+    template <bool UPD>
+    __device__ __forceinline__ Nodes fire(const Prep &pr, bool upd, uint32_t *top = nullptr) const
+    {
+        const uint32_t iv = upd ? inc : 0u;
         Nodes          n;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            const uint32_t a = addr(ss, b);
-            n.x[b]           = UPD ? add(a, (nsl >> b) & iv) : ld(a);
+            const uint32_t keep = (((0xFFu << (b + 1)) & 0xFFu) << kShift) | ((1u << kShift) - 1u);
+            const uint32_t a    = b == 7 ? A[7] : ((pr.t & keep) | (1u << (b + kShift)));
+            if (UPD && b == 7 && top) {
+                n.x[7] = *top;
+                *top += (pr.nsl >> 7) & iv;
+            } else
+                n.x[b] = UPD ? add(a, (pr.nsl >> b) & iv) : ld(a);
         }
         return n;
+    }
+    template <bool UPD>
+    __device__ __forceinline__ Nodes issue(uint32_t s, bool upd, uint32_t *top = nullptr) const
+    {
+        return fire<UPD>(prep(s), upd, top);
     }
     // Second half: (low, high) of get_frequency_range(s).  d256 = number of updates so far.
     // u = s * 0x8001 puts bit i of s at bits i and 15+i, so (u >> 2j) & 0x10001 is the pair
@@ -408,29 +429,34 @@ __device__ __forceinline__ uint64_t encode_symbol_spec(EncState &S, uint32_t lo,
     const double   Y  = __builtin_fma((double)R1, rc, rc);
     const uint32_t nlow   = S.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
     uint32_t       nihigh = 0u - (S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh));
-    asm volatile("" : "+v"(nihigh));
     const uint32_t x    = ~(nlow ^ nihigh);
     const uint32_t k    = x ? (uint32_t)__builtin_clz(x) : 32u;
-    const uint64_t sl   = (uint64_t)nlow << k;
+    const uint32_t P = S.pend;
+    // (Pz and k - 1 come out as one v_subrev_co -- borrow = "k == 0" -- and one v_cndmask on that
+    // borrow.  gfx950 wants two wait states between them and the compiler spends an s_nop on one;
+    // pinning both 64-bit shifts into the gap with one asm block costs a v_mov for the zero high
+    // half plus a conservative s_nop after the block: no gain.)
+    const uint64_t sl  = (uint64_t)nlow << k;
+    const uint32_t ih2 = (uint32_t)((uint64_t)nihigh << k);
+    const uint32_t Pz  = k ? P : 0u;
+    const uint32_t km1 = k - 1u;
     const uint32_t topk = (uint32_t)(sl >> 32);
     const uint32_t low2 = (uint32_t)sl;
-    const uint32_t ih2  = (uint32_t)((uint64_t)nihigh << k);
     const uint32_t t    = (low2 & ih2) << 1;
     const uint32_t j    = (uint32_t)__builtin_clz(~t);
     S.low   = (low2 << j) & 0x7FFFFFFFu;
     S.ihigh = (ih2 << j) & 0x7FFFFFFFu;
-    const uint32_t P  = S.pend;
-    const uint32_t Pz = k ? P : 0u;
     S.pend            = P - Pz + j;
     const uint32_t m  = k + Pz;
     uint32_t run;
-    asm("v_bfm_b32 %0, %1, %2" : "=v"(run) : "v"(Pz), "v"(k - 1u));
+    asm("v_bfm_b32 %0, %1, %2" : "=v"(run) : "v"(Pz), "v"(km1));
     S.acc = (S.acc << (m & 63u)) | (topk + run); // (the & 63 is what v_lshlrev_b64 does anyway: no instruction)
     const uint32_t nb = S.nb + m;                // garbage for a lane that raised the flag; everything below stays bounded
     if (nb >= 32) { // one exec-masked region: shift, byte swap, store, advance
 #ifndef REDUX_STORE_X4
         *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u)));
-        S.off += ST;
+        // in place: as plain C++ the sum lands in a new register and a v_mov merges it after the region
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(S.off) : "i"(ST) : "memory");
 #else
         emit_dword<false, ST>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u))), wbase, 0);
 #endif

@@ -335,19 +335,23 @@ constexpr int kPairStride = REDUX_ROWS ? 256 : 4;
 #ifndef REDUX_MODEL_DEPTH
 #define REDUX_MODEL_DEPTH 1
 #endif
+#ifndef REDUX_TOP_REG // 1: the model wave keeps node 128 (level 7) in a register while the model adapts
+#define REDUX_TOP_REG 1
+#endif
 template <bool UPD>
 __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, uint32_t lane, const uint4 cur,
-                                            uint32_t p, uint32_t nfreeze)
+                                            uint32_t p, uint32_t nfreeze, uint32_t *top = nullptr)
 {
+    constexpr int kInFlight = (UPD && REDUX_TOP_REG) ? 7 : 8; // LDS ops of one symbol
     const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
     auto sym = [&](int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; };
     // software pipeline: symbol i+1's LDS ops are in flight while symbol i's sums are formed
-    // (depths 2 and 3 measured no faster: the wave is bound by its own issue rate, not by LDS)
+    // (depths 2 and 3 measured no faster: the pair is bound by the VALU instructions of both waves, not by LDS latency)
     constexpr int D = REDUX_MODEL_DEPTH;
     Tree<true>::Nodes q[D + 1];
 #pragma unroll
     for (int d = 0; d < D; d++)
-        q[d] = T.template issue<UPD>(sym(d), true);
+        q[d] = T.template issue<UPD>(sym(d), true, top);
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const uint32_t s   = sym(i);
@@ -357,16 +361,30 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
         // complete in order, so lgkmcnt <= 8 means the ring half is written).
         const bool late = REDUX_KEEP8 && i == 7;
         if (i + D < 16 && !late) {
-            q[D] = T.template issue<UPD>(sym(i + D), true);
+            q[D] = T.template issue<UPD>(sym(i + D), true, top);
             __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t lo, hi;
         T.finish(s, nup, q[0], lo, hi);
+#ifdef REDUX_PROBE_MODEL // experiment: N extra independent VALU instructions per symbol in the model wave
+#pragma unroll
+        for (int k = 0; k < REDUX_PROBE_MODEL; k++) {
+            uint32_t dummy = lo;
+            asm volatile("v_add_u32 %0, %0, %1" : "+v"(dummy) : "v"(hi));
+        }
+#endif
+        // (lo and hi come out of v_dot2, and gfx950 wants three wait states between a dot result and an
+        // LDS instruction reading it: the compiler puts an s_nop 2 here.  Pinning the next symbol's
+        // address preparation into that gap removes the s_nop and changes nothing: the kernel is
+        // bound by the VALU instructions of both waves together, not by the wave's issue slots.)
         ring[i * 64 + lane] = make_uint2(lo, hi);
         if (late) {
             __builtin_amdgcn_sched_barrier(0);
-            q[D] = T.template issue<UPD>(sym(i + D), true);
-            asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+            q[D] = T.template issue<UPD>(sym(i + D), true, top);
+            if (kInFlight == 7)
+                asm volatile("s_waitcnt lgkmcnt(7)\n\ts_barrier" ::: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
         } else if ((i & 7) == 7)
             pair_barrier();
 #pragma unroll
@@ -419,11 +437,19 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
-            uint32_t       hi  = lh[i].y;
             // keeps ISel from turning (u64 >> 32) -> f64 into a 64-bit conversion (+1 v_add_f64); converting
-            // as signed avoids that too, but v_cvt_f64_i32 measured 9 % slower for the whole kernel
-            asm volatile("" : "+v"(hi));
+            // as signed avoids that too, but v_cvt_f64_i32 measured 9 % slower for the whole kernel.
+            // Applied to the ring value in place: on a copy it costs a v_mov per symbol, because the redo below reads lh[i] again.
+            asm volatile("" : "+v"(lh[i].y));
+            const uint32_t hi = lh[i].y;
             bad |= encode_symbol_spec<FIXUP, CB32, kPairStride>(S, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
+#ifdef REDUX_PROBE_CODER // experiment: N extra independent VALU instructions per symbol in the coder wave
+#pragma unroll
+            for (int k = 0; k < REDUX_PROBE_CODER; k++) {
+                uint32_t dummy = lh[i].x;
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(dummy) : "v"(hi));
+            }
+#endif
         }
         if (__builtin_expect(bad != 0, 0)) {
             S = S0;
@@ -590,8 +616,15 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
             };
 #define NEXT_CHUNK() next_chunk(p)
 #endif
+#if REDUX_TOP_REG
+            uint32_t top = 0; // node 128 in this lane's half, as the LDS dword would hold it
+            for (; p < a_end; p += 16)
+                model_chunk<true>(T, ring, lane, NEXT_CHUNK(), p, nfreeze, &top);
+            T.add(T.A[7], top); // from here on (freeze-crossing chunk, frozen chunks, the coder wave's tail) the tree is read from LDS
+#else
             for (; p < a_end; p += 16)
                 model_chunk<true>(T, ring, lane, NEXT_CHUNK(), p, nfreeze);
+#endif
             for (; p < m_end; p += 16) { // rolled: the update stops in the middle of this chunk
                 (void)NEXT_CHUNK();
                 for (uint32_t i = 0; i < 16; i++) {
