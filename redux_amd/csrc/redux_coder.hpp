@@ -421,8 +421,8 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
 // needed the careful path leaves garbage in acc/nb, but `off` still advances by at most one
 // dword per symbol and never beyond what the redo writes, so every stray store is overwritten.
 template <bool FIXUP, bool CB32, int ST = 4>
-__device__ __forceinline__ uint64_t encode_symbol_spec(EncState &S, uint32_t lo, uint32_t hi, uint32_t c, double rc,
-                                                       uint32_t sh_, uint8_t *wbase)
+__device__ __forceinline__ uint32_t encode_symbol_spec(EncState &S, uint32_t &nbm, uint32_t lo, uint32_t hi, uint32_t c,
+                                                       double rc, uint32_t sh_, uint8_t *wbase)
 {
     const uint32_t sh = CB32 ? 0u : sh_;
     const uint32_t R1 = (~(S.ihigh + S.low)) >> sh;
@@ -442,27 +442,36 @@ __device__ __forceinline__ uint64_t encode_symbol_spec(EncState &S, uint32_t lo,
     const uint32_t km1 = k - 1u;
     const uint32_t topk = (uint32_t)(sl >> 32);
     const uint32_t low2 = (uint32_t)sl;
-    const uint32_t t    = (low2 & ih2) << 1;
-    const uint32_t j    = (uint32_t)__builtin_clz(~t);
+    // j = leading ones of (low2 & ih2) << 1 = clz of its complement, formed as ((~(low2 & ih2)) << 1) | 1:
+    // a v_bitop3 (nand) and a v_lshl_or instead of and, shift, not
+    const uint32_t nt   = ((~(low2 & ih2)) << 1) | 1u;
+    const uint32_t j    = (uint32_t)__builtin_clz(nt);
     S.low   = (low2 << j) & 0x7FFFFFFFu;
     S.ihigh = (ih2 << j) & 0x7FFFFFFFu;
     S.pend            = P - Pz + j;
     const uint32_t m  = k + Pz;
     uint32_t run;
     asm("v_bfm_b32 %0, %1, %2" : "=v"(run) : "v"(Pz), "v"(km1));
-    S.acc = (S.acc << (m & 63u)) | (topk + run); // (the & 63 is what v_lshlrev_b64 does anyway: no instruction)
-    const uint32_t nb = S.nb + m;                // garbage for a lane that raised the flag; everything below stays bounded
-    if (nb >= 32) { // one exec-masked region: shift, byte swap, store, advance
+    // acc = (acc << m) | (topk + run): the low m bits of the shifted accumulator are zero and
+    // topk + run < 2^m, so the OR is an addition and the three terms are one v_add3_u32
+    // (the & 63 is what v_lshlrev_b64 does anyway: no instruction)
+    const uint64_t sa = S.acc << (m & 63u);
+    S.acc = (sa & 0xFFFFFFFF00000000ull) | (uint32_t)((uint32_t)sa + topk + run);
+    // nbm = (bits in the accumulator) - 32, in [-32, -1] between symbols: its sign is the "a dword
+    // is complete" test, its value the shift that extracts the dword, and OR-ing -32 takes the 32
+    // stored bits off again (a lane that raised the flag has garbage here; everything stays bounded)
+    const uint32_t nb = nbm + m;
+    if ((int32_t)nb >= 0) { // one exec-masked region: shift, byte swap, store, advance
 #ifndef REDUX_STORE_X4
-        *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u)));
+        *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb & 63u)));
         // in place: as plain C++ the sum lands in a new register and a v_mov merges it after the region
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(S.off) : "i"(ST) : "memory");
 #else
-        emit_dword<false, ST>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u))), wbase, 0);
+        emit_dword<false, ST>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb & 63u))), wbase, 0);
 #endif
     }
-    S.nb = nb & 31u;
-    return __builtin_amdgcn_ballot_w64(m > 32);
+    nbm = nb | 0xFFFFFFE0u;
+    return m; // the caller raises the flag if any m of the half exceeds 32
 }
 
 // The EOF tail (codec.rs:91-99) + flush_bits (bitio/mod.rs:183-198).  `shifts` is what

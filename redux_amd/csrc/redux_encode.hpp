@@ -432,8 +432,9 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
         // Eight symbols straight-line; the rare symbol whose pending run needs more than one
         // 32-bit append only raises a flag, and the half is then redone from the saved state
         // with the general encode_symbol (no per-symbol branch, no merge of two state versions).
-        const EncState S0 = S;
-        uint64_t       bad = 0;
+        const EncState S0  = S;
+        uint32_t       nbm = S.nb - 32u; // see encode_symbol_spec
+        uint32_t       mx  = 0;          // largest append of the half (pairs of symbols fold into one v_max3_u32)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
@@ -442,7 +443,8 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
             // Applied to the ring value in place: on a copy it costs a v_mov per symbol, because the redo below reads lh[i] again.
             asm volatile("" : "+v"(lh[i].y));
             const uint32_t hi = lh[i].y;
-            bad |= encode_symbol_spec<FIXUP, CB32, kPairStride>(S, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
+            const uint32_t m = encode_symbol_spec<FIXUP, CB32, kPairStride>(S, nbm, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
+            mx               = m > mx ? m : mx;
 #ifdef REDUX_PROBE_CODER // experiment: N extra independent VALU instructions per symbol in the coder wave
 #pragma unroll
             for (int k = 0; k < REDUX_PROBE_CODER; k++) {
@@ -451,6 +453,8 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
             }
 #endif
         }
+        S.nb = nbm + 32u;
+        const uint64_t bad = __builtin_amdgcn_ballot_w64(mx > 32u);
         if (__builtin_expect(bad != 0, 0)) {
             S = S0;
 #pragma unroll
