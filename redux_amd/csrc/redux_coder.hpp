@@ -252,13 +252,26 @@ __device__ __forceinline__ void enc_init(EncState &S, uint32_t off0) // codec.rs
 // `off` is always the byte offset of the NEXT dword; slots start 16-byte aligned.
 // ST: distance between a lane's consecutive dwords: 4 in a linear slot; 256 in a ROW-major group
 // area, where row r holds dword r of the group's 64 lanes (see Geometry in redux_hip.hip).
+// kSwapped, OR-ed into ST: the slot holds each dword as it leaves the accumulator (first stream
+// bit = bit 31 of a little-endian dword), i.e. byte-reversed inside every aligned dword; the
+// compaction kernel, which moves every byte anyway and has VALU to spare, restores the stream
+// order.  Saves the coder wave one v_perm per symbol.
+constexpr int kSwapped = 1 << 16;
+template <int ST>
+constexpr uint32_t stride_of = (uint32_t)(ST & 0xFFFF);
+template <int ST>
+__device__ __forceinline__ uint32_t stream_dword(uint32_t w) // w: the next 32 stream bits, first bit in bit 31
+{
+    return (ST & kSwapped) ? w : __builtin_bswap32(w);
+}
+
 template <bool CHECKED, int ST = 4>
 __device__ __forceinline__ void emit_dword(EncState &S, uint32_t w, uint8_t *wbase, uint32_t limit)
 {
 #ifndef REDUX_STORE_X4 // default: one 4-byte store per completed group
-    if (!CHECKED || S.off + ST <= limit)
+    if (!CHECKED || S.off + stride_of<ST> <= limit)
         *reinterpret_cast<uint32_t *>(wbase + S.off) = w;
-    S.off += ST;
+    S.off += stride_of<ST>;
 #else
     static_assert(ST == 4, "staged 16-byte stores need linear slots");
     S.q = make_uint4(S.q.y, S.q.z, S.q.w, w); // shift in place: the quad is stored as it stands
@@ -289,7 +302,7 @@ __device__ __forceinline__ void put_bits(EncState &S, uint32_t val, uint32_t m, 
     S.acc = (S.acc << m) | val; // m <= 32
     const uint32_t nb = S.nb + m;
     if (nb >= 32)
-        emit_dword<true, ST>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32))), wbase, limit);
+        emit_dword<true, ST>(S, stream_dword<ST>((uint32_t)(S.acc >> (nb - 32))), wbase, limit);
     S.nb = nb & 31u;
 }
 
@@ -420,24 +433,48 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
 // if it is non-zero, restores the copy and redoes the run with encode_symbol.  A symbol that
 // needed the careful path leaves garbage in acc/nb, but `off` still advances by at most one
 // dword per symbol and never beyond what the redo writes, so every stray store is overwritten.
+// What encode_symbol_spec carries from symbol to symbol besides EncState (spec_begin / spec_end
+// convert): nbm = bits in the accumulator - 32; r1 = high - low of the interval (what the next
+// symbol scales); ih = ~high left-aligned with a stray bit 31.
+struct SpecCarry {
+    uint32_t nbm, r1, ih;
+};
+__device__ __forceinline__ SpecCarry spec_begin(const EncState &S)
+{
+    SpecCarry C;
+    C.nbm = S.nb - 32u;
+    C.r1  = ~(S.ihigh + S.low);
+    C.ih  = S.ihigh;
+    return C;
+}
+__device__ __forceinline__ void spec_end(EncState &S, const SpecCarry &C)
+{
+    S.nb    = C.nbm + 32u;
+    S.ihigh = C.ih & 0x7FFFFFFFu;
+}
+
 template <bool FIXUP, bool CB32, int ST = 4>
-__device__ __forceinline__ uint32_t encode_symbol_spec(EncState &S, uint32_t &nbm, uint32_t lo, uint32_t hi, uint32_t c,
+__device__ __forceinline__ uint32_t encode_symbol_spec(EncState &S, SpecCarry &C, uint32_t lo, uint32_t hi, uint32_t c,
                                                        double rc, uint32_t sh_, uint8_t *wbase)
 {
     const uint32_t sh = CB32 ? 0u : sh_;
-    const uint32_t R1 = (~(S.ihigh + S.low)) >> sh;
+    const uint32_t R1 = C.r1 >> sh;
     const double   Y  = __builtin_fma((double)R1, rc, rc);
     const uint32_t nlow   = S.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
     uint32_t       nihigh = 0u - (S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh));
     const uint32_t x    = ~(nlow ^ nihigh);
-    const uint32_t k    = x ? (uint32_t)__builtin_clz(x) : 32u;
+    // 32-bit codes with count < 2^17 (!FIXUP): the interval is at least 2^30 wide before the
+    // symbol and 2^30 / 2^17 after it, so low != high, x != 0 and k <= 31: no "x == 0 -> 32" select
+    // and a 32-bit shift for ~high
+    constexpr bool kNonZero = CB32 && !FIXUP;
+    const uint32_t k    = kNonZero ? (uint32_t)__builtin_clz(x) : (x ? (uint32_t)__builtin_clz(x) : 32u);
     const uint32_t P = S.pend;
     // (Pz and k - 1 come out as one v_subrev_co -- borrow = "k == 0" -- and one v_cndmask on that
     // borrow.  gfx950 wants two wait states between them and the compiler spends an s_nop on one;
     // pinning both 64-bit shifts into the gap with one asm block costs a v_mov for the zero high
     // half plus a conservative s_nop after the block: no gain.)
     const uint64_t sl  = (uint64_t)nlow << k;
-    const uint32_t ih2 = (uint32_t)((uint64_t)nihigh << k);
+    const uint32_t ih2 = kNonZero ? nihigh << k : (uint32_t)((uint64_t)nihigh << k);
     const uint32_t Pz  = k ? P : 0u;
     const uint32_t km1 = k - 1u;
     const uint32_t topk = (uint32_t)(sl >> 32);
@@ -446,8 +483,14 @@ __device__ __forceinline__ uint32_t encode_symbol_spec(EncState &S, uint32_t &nb
     // a v_bitop3 (nand) and a v_lshl_or instead of and, shift, not
     const uint32_t nt   = ((~(low2 & ih2)) << 1) | 1u;
     const uint32_t j    = (uint32_t)__builtin_clz(nt);
-    S.low   = (low2 << j) & 0x7FFFFFFFu;
-    S.ihigh = (ih2 << j) & 0x7FFFFFFFu;
+    // The E3 steps drop bit 30 j times: shift by j, clear bit 31.  Bit 31 of both shifted values is
+    // the same (j >= 1: both had ones there; j == 0: both have 0 after the k shared bits), so the
+    // next interval width ~(low + ~high) is the same with or without the two clears (2 * 2^31 = 0
+    // mod 2^32) and only low, which is added to twice, gets its clear.
+    const uint32_t L = low2 << j;
+    C.ih             = ih2 << j;
+    C.r1             = ~(L + C.ih);
+    S.low            = L & 0x7FFFFFFFu;
     S.pend            = P - Pz + j;
     const uint32_t m  = k + Pz;
     uint32_t run;
@@ -460,17 +503,17 @@ __device__ __forceinline__ uint32_t encode_symbol_spec(EncState &S, uint32_t &nb
     // nbm = (bits in the accumulator) - 32, in [-32, -1] between symbols: its sign is the "a dword
     // is complete" test, its value the shift that extracts the dword, and OR-ing -32 takes the 32
     // stored bits off again (a lane that raised the flag has garbage here; everything stays bounded)
-    const uint32_t nb = nbm + m;
+    const uint32_t nb = C.nbm + m;
     if ((int32_t)nb >= 0) { // one exec-masked region: shift, byte swap, store, advance
 #ifndef REDUX_STORE_X4
-        *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb & 63u)));
+        *reinterpret_cast<uint32_t *>(wbase + S.off) = stream_dword<ST>((uint32_t)(S.acc >> (nb & 63u)));
         // in place: as plain C++ the sum lands in a new register and a v_mov merges it after the region
-        asm volatile("v_add_u32 %0, %1, %0" : "+v"(S.off) : "i"(ST) : "memory");
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(S.off) : "i"(stride_of<ST>) : "memory");
 #else
-        emit_dword<false, ST>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb & 63u))), wbase, 0);
+        emit_dword<false, ST>(S, stream_dword<ST>((uint32_t)(S.acc >> (nb & 63u))), wbase, 0);
 #endif
     }
-    nbm = nb | 0xFFFFFFE0u;
+    C.nbm = nb | 0xFFFFFFE0u;
     return m; // the caller raises the flag if any m of the half exceeds 32
 }
 
@@ -494,9 +537,9 @@ __device__ __forceinline__ uint32_t encode_finish(EncState &S, uint32_t shifts, 
     const uint32_t nbytes = (S.nb + 7) >> 3;
     const uint64_t tail   = S.nb ? (S.acc << (64 - S.nb)) : 0; // left-align, zero padding
     for (uint32_t i = 0; i < nbytes; i++) // nbytes <= 4: inside one dword in either layout
-        if (S.off + (ST == 4 ? i : (uint32_t)ST - 1u) < limit)
-            wbase[S.off + i] = (uint8_t)(tail >> (56 - 8 * i));
-    const uint32_t size = (S.off - off0) / ST * 4 + nbytes; // dropped stores are still counted
+        if (S.off + (stride_of<ST> != 4 ? stride_of<ST> - 1u : (ST & kSwapped) ? 3u : i) < limit) // (limit is a dword boundary in the swapped layout)
+            wbase[S.off + ((ST & kSwapped) ? 3u - i : i)] = (uint8_t)(tail >> (56 - 8 * i));
+    const uint32_t size = (S.off - off0) / stride_of<ST> * 4 + nbytes; // dropped stores are still counted
     S.off += nbytes;
     S.nb = 0;
     return size;

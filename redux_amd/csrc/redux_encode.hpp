@@ -331,7 +331,14 @@ struct ChunkQueue {
 #ifndef REDUX_ROWS // 1: the pair kernel writes ROW-major group areas (row r = dword r of the 64 lanes), k_compact_rows gathers them
 #define REDUX_ROWS 0
 #endif
-constexpr int kPairStride = REDUX_ROWS ? 256 : 4;
+#ifndef REDUX_PAIR_SWAP // 1: the pair kernel leaves the byte swap of every stream dword to the compaction (kSwapped, redux_coder.hpp)
+#if REDUX_ROWS || defined(REDUX_CODER_BRANCHY) || defined(REDUX_STORE_X4)
+#define REDUX_PAIR_SWAP 0
+#else
+#define REDUX_PAIR_SWAP 1
+#endif
+#endif
+constexpr int kPairStride = (REDUX_ROWS ? 256 : 4) | (REDUX_PAIR_SWAP ? kSwapped : 0);
 #ifndef REDUX_MODEL_DEPTH
 #define REDUX_MODEL_DEPTH 1
 #endif
@@ -433,7 +440,7 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
         // 32-bit append only raises a flag, and the half is then redone from the saved state
         // with the general encode_symbol (no per-symbol branch, no merge of two state versions).
         const EncState S0  = S;
-        uint32_t       nbm = S.nb - 32u; // see encode_symbol_spec
+        SpecCarry      C   = spec_begin(S);
         uint32_t       mx  = 0;          // largest append of the half (pairs of symbols fold into one v_max3_u32)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -443,7 +450,7 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
             // Applied to the ring value in place: on a copy it costs a v_mov per symbol, because the redo below reads lh[i] again.
             asm volatile("" : "+v"(lh[i].y));
             const uint32_t hi = lh[i].y;
-            const uint32_t m = encode_symbol_spec<FIXUP, CB32, kPairStride>(S, nbm, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
+            const uint32_t m = encode_symbol_spec<FIXUP, CB32, kPairStride>(S, C, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
             mx               = m > mx ? m : mx;
 #ifdef REDUX_PROBE_CODER // experiment: N extra independent VALU instructions per symbol in the coder wave
 #pragma unroll
@@ -453,7 +460,7 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
             }
 #endif
         }
-        S.nb = nbm + 32u;
+        spec_end(S, C);
         const uint64_t bad = __builtin_amdgcn_ballot_w64(mx > 32u);
         if (__builtin_expect(bad != 0, 0)) {
             S = S0;
@@ -585,7 +592,7 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
     const uint32_t sh      = 32 - a.code_bits;
     const uint32_t nfreeze = a.nfreeze;
     const rc_ptr   rc      = (rc_ptr)a.rc;
-    constexpr uint32_t kChunkBudget = (16 * 4 + 32) * (kPairStride / 4);
+    constexpr uint32_t kChunkBudget = (16 * 4 + 32) * (stride_of<kPairStride> / 4);
 
     // both waves derive the same chunk schedule from wave-uniform values
     uint32_t main_end = 0;

@@ -302,10 +302,10 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     const char *force = getenv("REDUX_ENCODE_KERNEL");
     const bool  pair  = g.u16 && a.aligned16 && a.lanes == 64 && !(force && !strcmp(force, "single"));
     // (a u16 tree means blocks of <= 65536 symbols, so count < 2^17: the pair kernel never needs FIXUP)
-#if REDUX_ROWS
-    if (pair && !g.fixup)
-        HIP_TRY(hipMemsetAsync(ws + g.off_mode, 1, 4, s));
-#endif
+    // what the pair kernel leaves in the slots (CompactArgs::mode): byte 0x01 -> row-major group
+    // areas, 0x02 -> linear slots whose dwords are byte-reversed
+    if (pair && !g.fixup && (REDUX_ROWS || REDUX_PAIR_SWAP))
+        HIP_TRY(hipMemsetAsync(ws + g.off_mode, REDUX_ROWS ? 1 : 2, 4, s));
     if (pair && !g.fixup && p->code_bits == 32)
         k_encode_pair<false, true><<<grid, 128, 0, s>>>(a);
     else if (pair && !g.fixup)

@@ -150,15 +150,19 @@ struct CompactArgs {
     int32_t        *status;
     int32_t        *summary;
     uint64_t        nblocks;
-    const uint32_t *mode;     // 0: linear slots (k_compact), != 0: row-major group areas (k_compact_rows)
+    const uint32_t *mode;     // bit 0: row-major group areas (k_compact_rows) instead of linear slots (k_compact);
+                              // bit 1: every aligned dword of a slot is byte-reversed (kSwapped, redux_coder.hpp)
     uint32_t        cap_rows; // rows of a group area
 };
 
 __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
 {
     const uint64_t b = blockIdx.x;
-    if (b >= a.nblocks || *a.mode != 0)
+    const uint32_t mode = *a.mode;
+    if (b >= a.nblocks || (mode & 1u))
         return;
+    const uint32_t bx  = (mode & 2u) ? 3u : 0u;                   // slot byte that holds stream byte i: i ^ bx
+    const uint32_t sel = (mode & 2u) ? 0x00010203u : 0x03020100u; // v_perm selector that restores stream order
     const uint64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
     const uint32_t tid = threadIdx.x;
     if (o1 > a.out_cap) { // the dense buffer is too small for this block: report, never write
@@ -181,7 +185,7 @@ __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
     if (head > n)
         head = n;
     if (tid < head)
-        dst[tid] = src[tid];
+        dst[tid] = src[tid ^ bx];
     // body: 16-byte dst chunks; the source is misaligned by the uniform amount `head`
     const uint32_t nchunks = (n - head) >> 4;
     const uint32_t dq = head >> 2, r = head & 3;
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
         uint32_t       v[5];
 #pragma unroll
         for (int k = 0; k < 5; k++)
-            v[k] = dq == 0 ? d[k] : dq == 1 ? d[k + 1] : dq == 2 ? d[k + 2] : d[k + 3];
+            v[k] = __builtin_amdgcn_perm(0u, dq == 0 ? d[k] : dq == 1 ? d[k + 1] : dq == 2 ? d[k + 2] : d[k + 3], sel);
         uint4 o;
         o.x = __builtin_amdgcn_alignbyte(v[1], v[0], r);
         o.y = __builtin_amdgcn_alignbyte(v[2], v[1], r);
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
     // tail
     const uint32_t done = head + (nchunks << 4);
     if (tid < n - done)
-        dst[done + tid] = src[done + tid];
+        dst[done + tid] = src[(done + tid) ^ bx];
 }
 
 // Row-major group areas (REDUX_ROWS): row r of group g holds dword r of its 64 streams
@@ -216,7 +220,7 @@ __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
 constexpr uint32_t kTileRows = 64;
 __global__ void __launch_bounds__(256) k_compact_rows(CompactArgs a)
 {
-    if (*a.mode == 0)
+    if ((*a.mode & 1u) == 0)
         return;
     __shared__ uint32_t tile[(kTileRows + 1) * 65]; // +1 leading row (source dword j-1); pitch 65: conflict-free column reads
     __shared__ uint64_t s_dst[64];                  // aligned dword that holds each stream's first byte (0: skip the stream)
