@@ -371,6 +371,9 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
             q[D] = T.template issue<UPD>(sym(i + D), true, top);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // (One hand-placed s_waitcnt per symbol -- everything behind symbol i's node values is known at
+        // compile time -- instead of the compiler's four, one in front of each v_perm, needs a
+        // sched_barrier to stay in front of finish() and measures 1 % slower.)
         uint32_t lo, hi;
         T.finish(s, nup, q[0], lo, hi);
 #ifdef REDUX_PROBE_MODEL // experiment: N extra independent VALU instructions per symbol in the model wave
