@@ -128,6 +128,27 @@ int redux_gen_iid_dev(void *d_out, uint64_t len, uint64_t first_byte, uint64_t s
 int redux_gen_zipf_dev(void *d_out, uint64_t len, uint64_t first_byte, uint64_t seed, void *stream);
 const uint32_t *redux_zipf_thresholds(void);
 
+/* ---- static-table model ------------------------------------------
+ * The reference's Codec is generic over its Model trait (src/model/mod.rs; lib.rs:14-15 invites
+ * custom models).  The cheapest second model is a fixed table: cum[0..=257] (host memory, 258
+ * entries) with cum[0] = 0, cum strictly increasing and cum[257] = total_frequency() <= freq_max.
+ * get_frequency(s) = [cum[s], cum[s+1]) for the data symbols 0..255 and for EOF = 256; nothing is
+ * updated.  Block b's stream is Codec::compress_stream (codec.rs:104-120) of that block under
+ * such a model.  Device path: symbol_bits == 8, code_bits <= 32 (else REDUX_UNSUPPORTED); a table
+ * that is not strictly increasing or exceeds freq_max is REDUX_INVALID_INPUT.
+ * Same buffers and error reporting as redux_encode_blocks_dev / redux_decode_blocks_dev. */
+int      redux_static_table_check(const redux_params *p, const uint32_t *cum);
+uint64_t redux_static_encode_bound(const redux_params *p, uint64_t in_len, uint32_t block_size);
+uint64_t redux_static_encode_workspace_bytes(const redux_params *p, uint64_t in_len, uint32_t block_size);
+int redux_static_encode_blocks_dev(const redux_params *p, const uint32_t *cum, const void *d_in, uint64_t in_len,
+                                   uint32_t block_size, void *d_out, uint64_t out_cap, void *d_out_offsets,
+                                   void *d_block_status, void *d_summary, void *d_workspace,
+                                   uint64_t workspace_bytes, void *stream);
+int redux_static_decode_blocks_dev(const redux_params *p, const uint32_t *cum, const void *d_in,
+                                   const void *d_in_offsets, uint64_t nblocks, uint32_t block_size, void *d_out,
+                                   uint64_t out_cap, void *d_out_sizes, void *d_block_status, void *d_summary,
+                                   void *stream);
+
 /* Library / build identification: "redux_hip <version> gfx950". */
 const char *redux_version(void);
 

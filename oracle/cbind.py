@@ -117,6 +117,31 @@ def decompress(data, params=(8, 30, 32), model=TREE, cap=None):
     return out[: bo.value].tobytes(), (bi.value, bo.value)
 
 
+def _static_call(fn, data, cum, params, cap):
+    a = _as_u8(data)
+    out = np.empty(cap, dtype=np.uint8)
+    tab = np.ascontiguousarray(np.asarray(cum, dtype=np.uint64))
+    bi, bo = C.c_uint64(), C.c_uint64()
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    st = fn(a.ctypes.data, len(a), out.ctypes.data, cap, params[0], params[1], params[2], tab.ctypes.data,
+            C.byref(bi), C.byref(bo))
+    if st:
+        raise OracleError(st)
+    return out[: bo.value].tobytes(), (bi.value, bo.value)
+
+
+def compress_static(data, cum, params=(8, 30, 32), cap=None):
+    """compress under the static-table model (ox_compress_static; not in the reference)."""
+    n = len(_as_u8(data))
+    return _static_call(lib().ox_compress_static, data, cum, params, cap if cap is not None else n * 5 + 1024)
+
+
+def decompress_static(data, cum, params=(8, 30, 32), cap=None):
+    n = len(_as_u8(data))
+    return _static_call(lib().ox_decompress_static, data, cum, params, cap if cap is not None else max(n * 64, 1 << 16))
+
+
 def block_count(n, block_size):
     return 1 if n == 0 else (n + block_size - 1) // block_size
 

@@ -291,6 +291,50 @@ static int tree_get_symbol(ox_model *m, uint64_t value, size_t *sym, uint64_t *l
     return OX_OK;
 }
 
+/* ---- static-table model: not in the reference.  The Model trait (src/model/mod.rs) with a fixed
+ * cumulative table v[0..=symbol_count]: get_frequency(s) = (v[s], v[s+1]), get_symbol(value) =
+ * the s with v[s] <= value < v[s+1], total_frequency() = v[symbol_count], no update.  The codec
+ * that drives it is the reference's (pinned as the header says); the model is this build's own
+ * (SURVEY.md section 8(f).4), so for it "parity" means device == this restatement. */
+static int static_get_frequency(ox_model *m, size_t symbol, uint64_t *lo, uint64_t *hi)
+{
+    if (symbol > m->params.symbol_eof)
+        return OX_INVALID_INPUT;
+    *lo = m->v[symbol];
+    *hi = m->v[symbol + 1];
+    return OX_OK;
+}
+
+static int static_get_symbol(ox_model *m, uint64_t value, size_t *sym, uint64_t *lo, uint64_t *hi)
+{
+    for (size_t i = 0; i + 1 < m->vlen; i++)
+        if (value < m->v[i + 1]) {
+            *sym = i;
+            *lo  = m->v[i];
+            *hi  = m->v[i + 1];
+            return OX_OK;
+        }
+    return OX_INVALID_INPUT;
+}
+
+/* cum: symbol_count + 1 entries (one per data symbol and EOF, then the total).  NULL if the table is not usable. */
+ox_model *ox_model_new_static(const ox_params *p, const uint64_t *cum)
+{
+    const size_t n = p->symbol_count + 1; /* symbol_count counts EOF (mod.rs:70) */
+    if (cum[0] != 0 || cum[n - 1] > p->freq_max)
+        return NULL;
+    for (size_t i = 0; i + 1 < n; i++)
+        if (cum[i + 1] <= cum[i])
+            return NULL;
+    ox_model *m = (ox_model *)calloc(1, sizeof *m);
+    m->kind   = OX_MODEL_STATIC;
+    m->params = *p;
+    m->vlen   = n;
+    m->v      = (uint64_t *)malloc(n * sizeof(uint64_t));
+    memcpy(m->v, cum, n * sizeof(uint64_t));
+    return m;
+}
+
 ox_model *ox_model_new(int kind, const ox_params *p)
 {
     ox_model *m = (ox_model *)calloc(1, sizeof *m);
@@ -319,17 +363,23 @@ void ox_model_free(ox_model *m)
 
 uint64_t ox_model_total_frequency(const ox_model *m)
 {
+    if (m->kind == OX_MODEL_STATIC)
+        return m->v[m->vlen - 1];
     return m->kind == OX_MODEL_LINEAR ? linear_total(m) : m->count;
 }
 
 int ox_model_get_frequency(ox_model *m, size_t symbol, uint64_t *low, uint64_t *high)
 {
+    if (m->kind == OX_MODEL_STATIC)
+        return static_get_frequency(m, symbol, low, high);
     return m->kind == OX_MODEL_LINEAR ? linear_get_frequency(m, symbol, low, high)
                                       : tree_get_frequency(m, symbol, low, high);
 }
 
 int ox_model_get_symbol(ox_model *m, uint64_t value, size_t *symbol, uint64_t *low, uint64_t *high)
 {
+    if (m->kind == OX_MODEL_STATIC)
+        return static_get_symbol(m, value, symbol, low, high);
     return m->kind == OX_MODEL_LINEAR ? linear_get_symbol(m, value, symbol, low, high)
                                       : tree_get_symbol(m, value, symbol, low, high);
 }
@@ -596,6 +646,51 @@ int ox_decompress(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap
         *bytes_out = w.buffer.count;
     ox_model_free(m);
     return e;
+}
+
+/* lib.rs:102-120 with the static-table model */
+static int static_run(int decode, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t symbol_bits,
+                      size_t freq_bits, size_t code_bits, const uint64_t *cum, uint64_t *bytes_in,
+                      uint64_t *bytes_out)
+{
+    ox_params p;
+    int       e = ox_params_new(symbol_bits, freq_bits, code_bits, &p);
+    if (e)
+        return e;
+    ox_model *m = ox_model_new_static(&p, cum);
+    if (!m)
+        return OX_INVALID_INPUT;
+    ox_codec     c;
+    ox_bitreader r;
+    ox_bitwriter w;
+    memset(&r, 0, sizeof r);
+    memset(&w, 0, sizeof w);
+    r.input  = in;
+    r.len    = in_len;
+    w.output = out;
+    w.cap    = out_cap;
+    codec_new(&c, m);
+    e = decode ? codec_decompress_stream(&c, &r, &w) : codec_compress_stream(&c, &r, &w);
+    if (bytes_in)
+        *bytes_in = r.buffer.count;
+    if (bytes_out)
+        *bytes_out = w.buffer.count;
+    ox_model_free(m);
+    return e;
+}
+
+int ox_compress_static(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t symbol_bits,
+                       size_t freq_bits, size_t code_bits, const uint64_t *cum, uint64_t *bytes_in,
+                       uint64_t *bytes_out)
+{
+    return static_run(0, in, in_len, out, out_cap, symbol_bits, freq_bits, code_bits, cum, bytes_in, bytes_out);
+}
+
+int ox_decompress_static(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t symbol_bits,
+                         size_t freq_bits, size_t code_bits, const uint64_t *cum, uint64_t *bytes_in,
+                         uint64_t *bytes_out)
+{
+    return static_run(1, in, in_len, out, out_cap, symbol_bits, freq_bits, code_bits, cum, bytes_in, bytes_out);
 }
 
 /* ======================================================================================

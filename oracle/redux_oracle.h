@@ -35,7 +35,7 @@ extern "C" {
 enum { OX_OK = 0, OX_EOF = 1, OX_INVALID_INPUT = 2, OX_IO_ERROR = 3 };
 
 /* model kinds: src/model/adaptive_linear.rs, src/model/adaptive_tree.rs */
-enum { OX_MODEL_LINEAR = 0, OX_MODEL_TREE = 1 };
+enum { OX_MODEL_LINEAR = 0, OX_MODEL_TREE = 1, OX_MODEL_STATIC = 2 /* this build's own, see ox_model_new_static */ };
 
 /* src/model/mod.rs:32-59  struct Parameters */
 typedef struct {
@@ -83,6 +83,16 @@ void      ox_model_get_freq_table(const ox_model *m, uint64_t *lows, uint64_t *h
 
 /* ---- whole-stream API (src/lib.rs:102-120) -------------------------------------- */
 /* compress: returns status; *bytes_in / *bytes_out are the (u64,u64) tuple of lib.rs:108. */
+/* Static-table model (not in the reference): cum has symbol_count + 1
+ * entries, cum[0] = 0, strictly increasing, cum[last] = total <= freq_max. */
+ox_model *ox_model_new_static(const ox_params *p, const uint64_t *cum);
+int ox_compress_static(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t symbol_bits,
+                       size_t freq_bits, size_t code_bits, const uint64_t *cum, uint64_t *bytes_in,
+                       uint64_t *bytes_out);
+int ox_decompress_static(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t symbol_bits,
+                         size_t freq_bits, size_t code_bits, const uint64_t *cum, uint64_t *bytes_in,
+                         uint64_t *bytes_out);
+
 int ox_compress(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
                 size_t symbol_bits, size_t freq_bits, size_t code_bits, int model_kind,
                 uint64_t *bytes_in, uint64_t *bytes_out);

@@ -167,6 +167,37 @@ class AdaptiveLinearModel:
         raise InvalidInput()
 
 
+class StaticModel:
+    """Not in the reference: the Model interface (src/model/mod.rs) over a fixed cumulative table
+    cum[0..=symbol_count].  No update."""
+
+    def __init__(self, p, cum):
+        cum = [int(x) for x in cum]
+        if len(cum) != p.symbol_count + 1 or cum[0] != 0 or cum[-1] > p.freq_max:
+            raise InvalidInput()
+        if any(b <= a for a, b in zip(cum, cum[1:])):
+            raise InvalidInput()
+        self.params = p
+        self.cum = cum
+
+    def parameters(self):
+        return self.params
+
+    def total_frequency(self):
+        return self.cum[-1]
+
+    def get_frequency(self, symbol):
+        if symbol > self.params.symbol_eof:
+            raise InvalidInput()
+        return (self.cum[symbol], self.cum[symbol + 1])
+
+    def get_symbol(self, value):
+        for i in range(len(self.cum) - 1):
+            if value < self.cum[i + 1]:
+                return (i, self.cum[i], self.cum[i + 1])
+        raise InvalidInput()
+
+
 class AdaptiveTreeModel:
     """src/model/adaptive_tree.rs"""
 

@@ -8,5 +8,5 @@ from .api import (  # noqa: F401
     Error, Eof, InvalidInput, IoError, OutputTooSmall, Unsupported,
     Parameters, AdaptiveTreeModel,
     compress, decompress, compress_blocks, decompress_blocks,
-    DeviceEncoder, DeviceDecoder, gen_iid, gen_zipf, zipf_thresholds, version,
+    DeviceEncoder, DeviceDecoder, DeviceStaticCoder, gen_iid, gen_zipf, zipf_thresholds, version,
 )

@@ -41,6 +41,11 @@ SIGNATURES = {
     "redux_decode_blocks_dev": (C.c_int, [_PP, _V, _V, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
     "redux_encode_slots_dev": (C.c_int, [_PP, _V, _U64, _U32, _V, _V, _U64, _V]),
     "redux_compact_slots_dev": (C.c_int, [_PP, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
+    "redux_static_table_check": (C.c_int, [_PP, C.POINTER(_U32)]),
+    "redux_static_encode_bound": (_U64, [_PP, _U64, _U32]),
+    "redux_static_encode_workspace_bytes": (_U64, [_PP, _U64, _U32]),
+    "redux_static_encode_blocks_dev": (C.c_int, [_PP, C.POINTER(_U32), _V, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
+    "redux_static_decode_blocks_dev": (C.c_int, [_PP, C.POINTER(_U32), _V, _V, _U64, _U32, _V, _U64, _V, _V, _V, _V]),
     "redux_gen_iid_dev": (C.c_int, [_V, _U64, _U64, _U64, _V]),
     "redux_gen_zipf_dev": (C.c_int, [_V, _U64, _U64, _U64, _V]),
     "redux_zipf_thresholds": (C.POINTER(_U32), []),

@@ -318,6 +318,65 @@ class DeviceDecoder:
         return self.out[: nb * self.block_size], self.sizes[:nb], self.status[:nb], self.summary
 
 
+class DeviceStaticCoder:
+    """The coder core under a fixed frequency table (include/redux_hip.h
+    "static-table model").  cum: 258 cumulative frequencies, cum[0] = 0, strictly increasing,
+    cum[257] = total <= freq_max; symbol 256 is EOF.  Same buffers as DeviceEncoder/DeviceDecoder."""
+
+    def __init__(self, params, cum, block_size, max_in_len, device="cuda:0"):
+        torch = _torch()
+        self.P = _params_of(params)
+        self.cp = self.P._c()
+        L = _lib.lib()
+        self.cum = (C.c_uint32 * 258)(*[int(x) for x in cum])
+        _raise(L.redux_static_table_check(C.byref(self.cp), self.cum))
+        self.block_size = int(block_size)
+        self.max_in_len = int(max_in_len)
+        self.nblocks_max = L.redux_block_count(self.max_in_len, self.block_size)
+        self.ws_bytes = L.redux_static_encode_workspace_bytes(C.byref(self.cp), self.max_in_len, self.block_size)
+        self.out_cap = L.redux_static_encode_bound(C.byref(self.cp), self.max_in_len, self.block_size)
+        self.device = torch.device(device)
+        self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        self.ws_off = (-self.ws.data_ptr()) % 256
+        self.out = torch.empty(self.out_cap, dtype=torch.uint8, device=self.device)
+        self.offsets = torch.zeros(self.nblocks_max + 1, dtype=torch.int64, device=self.device)
+        self.status = torch.zeros(self.nblocks_max, dtype=torch.int32, device=self.device)
+        self.summary = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.dec_out = None
+
+    def encode(self, d_in):
+        torch = _torch()
+        n = d_in.numel()
+        assert d_in.dtype == torch.uint8 and d_in.is_contiguous() and n <= self.max_in_len
+        self.summary.zero_()
+        st = _lib.lib().redux_static_encode_blocks_dev(
+            C.byref(self.cp), self.cum, C.c_void_p(d_in.data_ptr()), n, self.block_size, C.c_void_p(self.out.data_ptr()),
+            self.out_cap, C.c_void_p(self.offsets.data_ptr()), C.c_void_p(self.status.data_ptr()),
+            C.c_void_p(self.summary.data_ptr()), C.c_void_p(self.ws.data_ptr() + self.ws_off), self.ws_bytes,
+            _stream_ptr(torch))
+        _raise(st)
+        nb = _lib.lib().redux_block_count(n, self.block_size)
+        return self.out, self.offsets[: nb + 1], self.status[:nb], self.summary
+
+    def decode(self, d_streams, d_offsets):
+        torch = _torch()
+        nb = d_offsets.numel() - 1
+        assert nb <= self.nblocks_max and d_offsets.dtype == torch.int64 and d_streams.dtype == torch.uint8
+        if self.dec_out is None:
+            self.dec_out = torch.empty(self.nblocks_max * self.block_size, dtype=torch.uint8, device=self.device)
+            self.dec_sizes = torch.zeros(self.nblocks_max, dtype=torch.int32, device=self.device)
+            self.dec_status = torch.zeros(self.nblocks_max, dtype=torch.int32, device=self.device)
+            self.dec_summary = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.dec_summary.zero_()
+        st = _lib.lib().redux_static_decode_blocks_dev(
+            C.byref(self.cp), self.cum, C.c_void_p(d_streams.data_ptr()), C.c_void_p(d_offsets.data_ptr()), nb,
+            self.block_size, C.c_void_p(self.dec_out.data_ptr()), self.dec_out.numel(),
+            C.c_void_p(self.dec_sizes.data_ptr()), C.c_void_p(self.dec_status.data_ptr()),
+            C.c_void_p(self.dec_summary.data_ptr()), _stream_ptr(torch))
+        _raise(st)
+        return self.dec_out[: nb * self.block_size], self.dec_sizes[:nb], self.dec_status[:nb], self.dec_summary
+
+
 # ---- synthetic workloads (BASELINE.json configs 2 and 5) ------------------------------------
 def gen_iid(nbytes, seed=0x5EED0001, first_byte=0, device="cuda:0", out=None):
     torch = _torch()

@@ -7,6 +7,7 @@
 //   redux_pack.hpp     k_scan_sizes, k_compact: slots -> dense stream + offsets
 //   redux_any.hpp      general Parameters (symbol_bits <= 16, code_bits <= 63), one lane per block
 //   redux_synth.hpp    k_gen_iid / k_gen_zipf
+//   redux_static.hpp   k_encode_static / k_decode_static: the coder core under a fixed frequency table
 // This file holds the general-parameter kernels' launch shims, the workspace geometry and the
 // extern "C" entry points.
 //
@@ -17,6 +18,7 @@
 #include "redux_decode.hpp"
 #include "redux_pack.hpp"
 #include "redux_synth.hpp"
+#include "redux_static.hpp"
 
 #include "../../include/redux_hip.h"
 
@@ -147,12 +149,15 @@ static uint64_t slot_cap_for(const redux_params *p, uint32_t block_size)
     return bits / 8 + 1024;
 }
 
-static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_size)
+// static_model: the fixed-table coder (redux_static.hpp).  A symbol of frequency >= 1 out of
+// total <= freq_max costs at most freq_bits bits + 1 for the truncation of codec.rs:59-60, + 1
+// spare; no reciprocal table, no tree.
+static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_size, bool static_model = false)
 {
     Geometry g;
     memset(&g, 0, sizeof g);
     g.nblocks = in_len == 0 ? 1 : (in_len + block_size - 1) / block_size;
-    const uint64_t cap = slot_cap_for(p, block_size);
+    const uint64_t cap = static_model ? ((uint64_t)block_size + 1) * (p->freq_bits + 2) / 8 + 1024 : slot_cap_for(p, block_size);
     g.slot_cap   = cap > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)cap;
     // Slot stride: a whole number of 128-byte lines, and an ODD one.  All lanes write their
     // slots at about the same relative offset, so a stride that is a multiple of 2^k lines
@@ -168,7 +173,9 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.u16   = block_size <= 65536;
     g.fixup = (257ull + (uint64_t)(g.rc_n - 1)) >= (1ull << 17);
     g.rc_n += 32; // slack: both coders load their reciprocals a group / a chunk ahead without clamping
-    g.any = is_any(p);
+    g.any = !static_model && is_any(p);
+    if (static_model)
+        g.rc_n = 0;
     if (g.any) { // no reciprocal table; one tree of 2^symbol_bits + 2 u32 per block
         g.rc_n       = 0;
         g.u16        = false;
@@ -320,16 +327,12 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     return REDUX_OK;
 }
 
-int redux_compact_slots_dev(const redux_params *p, uint64_t in_len, uint32_t block_size, void *d_out,
-                            uint64_t out_cap, void *d_out_offsets, void *d_block_status, void *d_summary,
-                            void *d_workspace, uint64_t workspace_bytes, void *stream)
+// scan + gather of the slots a coder kernel left in the workspace laid out by g
+static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *d_out_offsets, void *d_block_status,
+                        void *d_summary, void *d_workspace, uint64_t workspace_bytes, void *stream)
 {
-    int st = check_params(p);
-    if (st != REDUX_OK)
-        return st;
-    if (block_size == 0 || !d_workspace || !d_block_status || !d_out_offsets || !d_out)
+    if (!d_workspace || !d_block_status || !d_out_offsets || !d_out)
         return REDUX_INVALID_INPUT;
-    const Geometry g = geometry(p, in_len, block_size);
     if (workspace_bytes < g.total)
         return REDUX_OUTPUT_TOO_SMALL;
     hipStream_t s  = (hipStream_t)stream;
@@ -363,6 +366,19 @@ int redux_compact_slots_dev(const redux_params *p, uint64_t in_len, uint32_t blo
 #endif
     HIP_TRY(hipGetLastError());
     return REDUX_OK;
+}
+
+int redux_compact_slots_dev(const redux_params *p, uint64_t in_len, uint32_t block_size, void *d_out,
+                            uint64_t out_cap, void *d_out_offsets, void *d_block_status, void *d_summary,
+                            void *d_workspace, uint64_t workspace_bytes, void *stream)
+{
+    int st = check_params(p);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0)
+        return REDUX_INVALID_INPUT;
+    return compact_with(geometry(p, in_len, block_size), d_out, out_cap, d_out_offsets, d_block_status, d_summary,
+                        d_workspace, workspace_bytes, stream);
 }
 
 int redux_encode_blocks_dev(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size,
@@ -663,6 +679,132 @@ int redux_decompress(const redux_params *p, const uint8_t *in, uint64_t in_len, 
             *bytes_in = used;
     }
     return rc;
+}
+
+// ---- static-table model (redux_static.hpp) ----------------------------
+static int static_check(const redux_params *p, const uint32_t *cum)
+{
+    int st = check_params(p);
+    if (st != REDUX_OK)
+        return st;
+    if (is_any(p)) // 8-bit symbols, code_bits <= 32: the widths the fast coder core covers
+        return REDUX_UNSUPPORTED;
+    if (!cum || cum[0] != 0)
+        return REDUX_INVALID_INPUT;
+    for (uint32_t i = 0; i + 1 < kStaticEntries; i++)
+        if (cum[i + 1] <= cum[i]) // every symbol, EOF included, must be codable
+            return REDUX_INVALID_INPUT;
+    if ((uint64_t)cum[kStaticEntries - 1] > (1ull << p->freq_bits) - 1) // total <= freq_max (model/mod.rs)
+        return REDUX_INVALID_INPUT;
+    return REDUX_OK;
+}
+
+static double static_rc(uint32_t total)
+{
+    double  r = 1.0 / (double)total;
+    int64_t b;
+    memcpy(&b, &r, 8);
+    b += 4; // as k_fill_rc: never below the true quotient (scale_div)
+    memcpy(&r, &b, 8);
+    return r;
+}
+
+int redux_static_table_check(const redux_params *p, const uint32_t *cum) { return static_check(p, cum); }
+
+uint64_t redux_static_encode_bound(const redux_params *p, uint64_t in_len, uint32_t block_size)
+{
+    if (check_params(p) != REDUX_OK || is_any(p) || block_size == 0)
+        return 0;
+    const Geometry g = geometry(p, in_len, block_size, true);
+    return g.nblocks * (uint64_t)g.slot_cap;
+}
+
+uint64_t redux_static_encode_workspace_bytes(const redux_params *p, uint64_t in_len, uint32_t block_size)
+{
+    if (check_params(p) != REDUX_OK || is_any(p) || block_size == 0)
+        return 0;
+    return geometry(p, in_len, block_size, true).total;
+}
+
+int redux_static_encode_blocks_dev(const redux_params *p, const uint32_t *cum, const void *d_in, uint64_t in_len,
+                                   uint32_t block_size, void *d_out, uint64_t out_cap, void *d_out_offsets,
+                                   void *d_block_status, void *d_summary, void *d_workspace,
+                                   uint64_t workspace_bytes, void *stream)
+{
+    int st = static_check(p, cum);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0 || (!d_in && in_len) || !d_block_status || !d_workspace)
+        return REDUX_INVALID_INPUT;
+    if (((uintptr_t)d_workspace) & 255)
+        return REDUX_INVALID_INPUT;
+    const Geometry g = geometry(p, in_len, block_size, true);
+    if (workspace_bytes < g.total)
+        return REDUX_OUTPUT_TOO_SMALL;
+    if (64ull * g.slot_bytes >= (1ull << 32)) // 64 slots within a 32-bit lane offset
+        return REDUX_UNSUPPORTED;
+    hipStream_t s  = (hipStream_t)stream;
+    uint8_t    *ws = (uint8_t *)d_workspace;
+    HIP_TRY(hipMemsetAsync(ws + g.off_mode, 0, 256, s)); // linear slots, stream byte order
+    StaticEncArgs a;
+    a.in         = (const uint8_t *)d_in;
+    a.in_len     = in_len;
+    a.nblocks    = g.nblocks;
+    a.slots      = ws + g.off_slots;
+    a.slot_bytes = g.slot_bytes;
+    a.sizes      = (uint32_t *)(ws + g.off_sizes);
+    a.status     = (int32_t *)d_block_status;
+    a.rc         = static_rc(cum[kStaticEntries - 1]);
+    a.block_size = block_size;
+    a.slot_cap   = g.slot_cap;
+    a.code_bits  = p->code_bits;
+    a.aligned16  = ((((uintptr_t)d_in) & 15) == 0 && (block_size & 15) == 0) ? 1 : 0;
+    memcpy(a.tab.cum, cum, sizeof a.tab.cum);
+    const uint32_t grid = (uint32_t)((g.nblocks + 63) / 64);
+    if (cum[kStaticEntries - 1] >= (1u << 17))
+        k_encode_static<true><<<grid, 64, 0, s>>>(a);
+    else
+        k_encode_static<false><<<grid, 64, 0, s>>>(a);
+    HIP_TRY(hipGetLastError());
+    return compact_with(g, d_out, out_cap, d_out_offsets, d_block_status, d_summary, d_workspace, workspace_bytes, stream);
+}
+
+int redux_static_decode_blocks_dev(const redux_params *p, const uint32_t *cum, const void *d_in,
+                                   const void *d_in_offsets, uint64_t nblocks, uint32_t block_size, void *d_out,
+                                   uint64_t out_cap, void *d_out_sizes, void *d_block_status, void *d_summary,
+                                   void *stream)
+{
+    int st = static_check(p, cum);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0 || !d_in_offsets || !d_out_sizes || !d_block_status)
+        return REDUX_INVALID_INPUT;
+    if (nblocks == 0)
+        return REDUX_OK;
+    if (out_cap < nblocks * (uint64_t)block_size)
+        return REDUX_OUTPUT_TOO_SMALL;
+    hipStream_t   s = (hipStream_t)stream;
+    StaticDecArgs a;
+    a.in         = (const uint8_t *)d_in;
+    a.in_offsets = (const uint64_t *)d_in_offsets;
+    a.nblocks    = nblocks;
+    a.out        = (uint8_t *)d_out;
+    a.out_sizes  = (uint32_t *)d_out_sizes;
+    a.status     = (int32_t *)d_block_status;
+    a.rc         = static_rc(cum[kStaticEntries - 1]);
+    a.block_size = block_size;
+    a.code_bits  = p->code_bits;
+    a.aligned4   = ((((uintptr_t)d_out) & 3) == 0 && (block_size & 3) == 0) ? 1 : 0;
+    memcpy(a.tab.cum, cum, sizeof a.tab.cum);
+    const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
+    if (cum[kStaticEntries - 1] >= (1u << 17))
+        k_decode_static<true><<<grid, 64, 0, s>>>(a);
+    else
+        k_decode_static<false><<<grid, 64, 0, s>>>(a);
+    if (d_summary)
+        k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
+    HIP_TRY(hipGetLastError());
+    return REDUX_OK;
 }
 
 int redux_gen_iid_dev(void *d_out, uint64_t len, uint64_t first_byte, uint64_t seed, void *stream)

@@ -128,3 +128,22 @@ def test_cpp_host_mirror_compiles_and_validates(tmp_path):
     exe = build_host_mirror_test(tmp_path)
     out = subprocess.run([exe, "--no-gpu"], capture_output=True, text=True)
     assert out.returncode == 0 and "host-side checks ok" in out.stdout, out.stderr
+
+
+def test_static_table_check_is_host_side():
+    """redux_static_table_check validates the table on the host (no GPU call): strictly increasing,
+    cum[0] = 0, total <= freq_max; only the widths of the fast coder core are supported."""
+    import ctypes as C
+    from redux_amd import _lib
+    L = _lib.lib()
+    tab = lambda xs: (C.c_uint32 * 258)(*xs)
+    flat = list(range(258))
+    ok = _lib.Params(8, 30, 32)
+    assert L.redux_static_table_check(C.byref(ok), tab(flat)) == _lib.OK
+    assert L.redux_static_table_check(C.byref(ok), tab([1] + flat[1:])) == _lib.INVALID_INPUT
+    assert L.redux_static_table_check(C.byref(ok), tab(flat[:50] + [flat[49]] + flat[51:])) == _lib.INVALID_INPUT
+    small = _lib.Params(8, 14, 16)
+    assert L.redux_static_table_check(C.byref(small), tab([i * 100 for i in range(258)])) == _lib.INVALID_INPUT
+    assert L.redux_static_table_check(C.byref(_lib.Params(12, 20, 32)), tab(flat)) == _lib.UNSUPPORTED
+    assert L.redux_static_encode_workspace_bytes(C.byref(ok), 1 << 20, 65536) > 0
+    assert L.redux_static_encode_bound(C.byref(ok), 1 << 20, 65536) >= (1 << 20) * 4

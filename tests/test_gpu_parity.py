@@ -391,6 +391,74 @@ def test_encoder_role_book_is_returned(rx, nblocks):
         assert firsts[1][int(offs_h[b]): int(offs_h[b + 1])].cpu().numpy().tobytes() == want, b
 
 
+def _static_tables():
+    from test_oracle_codec import static_tables
+    return static_tables()
+
+
+@pytest.mark.parametrize("name", ["flat", "skewed", "wide", "narrow16"])
+def test_static_model_matches_oracle(rx, name):
+    """the coder core under a fixed frequency table.  Every block's stream equals
+    the oracle's compress with the same static model (the codec is the reference's, the model is
+    this build's: device == restatement is the bar), and the device decoder inverts it."""
+    import torch
+    params, cum = _static_tables()[name]
+    rng = np.random.default_rng(11)
+    for bs, n in ((4096, 4096 * 70 + 123), (65536, 65536 * 3 + 1), (1000, 0), (48, 48 * 129)):
+        host = rng.integers(0, 256, n, dtype=np.uint8)
+        if n > 5000:
+            host[1000:3000] = 255           # the last data symbol, next to EOF in the table
+            host[3000:5000] = 0
+        d_in = torch.from_numpy(host).cuda()
+        coder = rx.DeviceStaticCoder(params, cum, bs, max(n, 1))
+        out, offs, status, summary = coder.encode(d_in)
+        torch.cuda.synchronize()
+        assert summary.tolist() == [0, 0]
+        nb = offs.numel() - 1
+        offs_h = offs.cpu().numpy()
+        out_h = out[: int(offs_h[-1])].cpu().numpy()
+        check = range(nb) if nb <= 80 else sorted({0, 1, 63, 64, nb // 2, nb - 2, nb - 1})
+        for b in check:
+            want, _ = ox.compress_static(host[b * bs:(b + 1) * bs].tobytes(), cum, params)
+            assert out_h[int(offs_h[b]): int(offs_h[b + 1])].tobytes() == want, (name, bs, b)
+        d_out, d_sizes, d_status, d_sum = coder.decode(out[: int(offs_h[-1])], offs)
+        torch.cuda.synchronize()
+        assert d_sum.tolist() == [0, 0]
+        got = d_out.cpu().numpy()
+        sizes = d_sizes.cpu().numpy()
+        for b in range(nb):
+            lo = b * bs
+            ln = min(bs, n - lo) if n else 0
+            assert sizes[b] == ln and (got[lo: lo + ln] == host[lo: lo + ln]).all(), (name, bs, b)
+
+
+def test_static_model_errors(rx):
+    import torch
+    flat = list(range(258))
+    with pytest.raises(rx.InvalidInput):
+        rx.DeviceStaticCoder((8, 30, 32), flat[:100] + [flat[99]] + flat[101:], 4096, 4096)
+    with pytest.raises(rx.InvalidInput):
+        rx.DeviceStaticCoder((8, 14, 16), [i * 100 for i in range(258)], 4096, 4096)  # total > freq_max
+    with pytest.raises(rx.Unsupported):
+        rx.DeviceStaticCoder((12, 20, 32), flat, 4096, 4096)
+    # a truncated stream decodes to Err(Eof) for that block only, as with the adaptive model
+    coder = rx.DeviceStaticCoder((8, 30, 32), flat, 4096, 8192)
+    d_in = torch.arange(8192, dtype=torch.int32).to(torch.uint8).cuda()
+    out, offs, _, _ = coder.encode(d_in)
+    torch.cuda.synchronize()
+    offs2 = offs.clone()
+    cut = offs.clone()
+    cut[1] = offs[1] - 40  # block 0 loses its last 40 bytes (block 1 still starts at offs[1])
+    streams = torch.cat([out[: int(cut[1])], out[int(offs[1]): int(offs[2])]])
+    offs2[1] = cut[1]
+    offs2[2] = cut[1] + (offs[2] - offs[1])
+    d_out, d_sizes, d_status, d_sum = coder.decode(streams, offs2)
+    torch.cuda.synchronize()
+    assert d_status.tolist()[0] == 1 and d_status.tolist()[1] == 0  # REDUX_EOF, REDUX_OK
+    assert d_sum.tolist() == [1, 1]
+    assert torch.equal(d_out[4096:8192], d_in[4096:8192])
+
+
 def test_dense_output_too_small_is_reported_not_overrun(rx):
     import ctypes as C
     import torch

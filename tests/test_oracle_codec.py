@@ -173,3 +173,43 @@ def test_general_parameters_c_equals_python(params):
         assert d == d2 and dc == dc2
         whole = (len(data) * 8 // params[0]) * params[0] // 8  # bytes made only of whole symbols
         assert d == data[: len(d)] and len(d) >= whole - 1 and dc[0] == len(s)
+
+
+# ---- static-table model (not in the reference: C restatement vs Python) --------
+def static_tables():
+    """name -> (params, cum[258])"""
+    import random as _r
+    t = {}
+    t["flat"] = ((8, 30, 32), list(range(258)))                        # every symbol frequency 1
+    rng = _r.Random(7)
+    f = [1 + int(4000 * rng.random() ** 6) for _ in range(257)]         # skewed, total ~ 2^16
+    t["skewed"] = ((8, 30, 32), [0] + [sum(f[: i + 1]) for i in range(257)])
+    g = [1 + (997 * i) % 8191 for i in range(257)]                      # total ~ 2^20: the fix-up division
+    t["wide"] = ((8, 30, 32), [0] + [sum(g[: i + 1]) for i in range(257)])
+    h = [1 + (i % 7) * 9 for i in range(257)]                           # total < 2^14 - 1 for 16-bit codes
+    t["narrow16"] = ((8, 14, 16), [0] + [sum(h[: i + 1]) for i in range(257)])
+    return t
+
+
+@pytest.mark.parametrize("name", sorted(static_tables()))
+def test_static_model_c_equals_python_and_roundtrips(name):
+    params, cum = static_tables()[name]
+    rng = random.Random(hash(name) & 0xFFFF)
+    P = rr.Parameters(*params)
+    for data in (b"", b"a", bytes(rng.randrange(256) for _ in range(700)), b"abracadabra" * 40, bytes([255]) * 300):
+        c_stream, c_counts = ox.compress_static(data, cum, params)
+        p_stream, p_counts = rr.compress(data, rr.StaticModel(P, cum))
+        assert c_stream == p_stream and tuple(c_counts) == tuple(p_counts), name
+        back, _ = ox.decompress_static(c_stream, cum, params)
+        assert back == data
+        assert rr.decompress(c_stream, rr.StaticModel(P, cum))[0] == data
+
+
+def test_static_model_rejects_bad_tables():
+    P = rr.Parameters(8, 14, 16)
+    flat = list(range(258))
+    for bad in (flat[:-1], [1] + flat[1:], flat[:100] + [flat[99]] + flat[101:], [i * 100 for i in range(258)]):
+        with pytest.raises(rr.InvalidInput):
+            rr.StaticModel(P, bad)
+    with pytest.raises(ox.OracleError):
+        ox.compress_static(b"x", [i * 100 for i in range(258)], (8, 14, 16))  # total > freq_max
