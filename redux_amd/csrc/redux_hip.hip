@@ -741,7 +741,7 @@ int redux_static_encode_blocks_dev(const redux_params *p, const uint32_t *cum, c
     const Geometry g = geometry(p, in_len, block_size, true);
     if (workspace_bytes < g.total)
         return REDUX_OUTPUT_TOO_SMALL;
-    if (64ull * g.slot_bytes >= (1ull << 32)) // 64 slots within a 32-bit lane offset
+    if (64ull * g.slot_bytes >= (1ull << 32) || 64ull * block_size >= (1ull << 32)) // 64 slots / blocks within a 32-bit lane offset
         return REDUX_UNSUPPORTED;
     hipStream_t s  = (hipStream_t)stream;
     uint8_t    *ws = (uint8_t *)d_workspace;
@@ -762,9 +762,11 @@ int redux_static_encode_blocks_dev(const redux_params *p, const uint32_t *cum, c
     memcpy(a.tab.cum, cum, sizeof a.tab.cum);
     const uint32_t grid = (uint32_t)((g.nblocks + 63) / 64);
     if (cum[kStaticEntries - 1] >= (1u << 17))
-        k_encode_static<true><<<grid, 64, 0, s>>>(a);
+        k_encode_static<true, false><<<grid, 64, 0, s>>>(a);
+    else if (p->code_bits == 32)
+        k_encode_static<false, true><<<grid, 64, 0, s>>>(a);
     else
-        k_encode_static<false><<<grid, 64, 0, s>>>(a);
+        k_encode_static<false, false><<<grid, 64, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     return compact_with(g, d_out, out_cap, d_out_offsets, d_block_status, d_summary, d_workspace, workspace_bytes, stream);
 }

@@ -53,7 +53,36 @@ struct StaticEncArgs {
     StaticTable    tab;
 };
 
-template <bool FIXUP>
+// Sixteen data symbols straight-line, all 64 lanes active, stores unchecked (the caller has
+// checked the chunk's budget): encode_symbol_spec as in the adaptive coder wave, with the same
+// "redo the stretch from the saved state with the general encode_symbol if any lane needed more
+// than one 32-bit append" rule.  The two table reads of a symbol are one ds_read2_b32.
+template <bool FIXUP, bool CB32>
+__device__ __forceinline__ void static_chunk(EncState &S, const uint32_t *tab, const uint4 cur, uint32_t c, double rc,
+                                             uint32_t sh, uint8_t *wdst)
+{
+    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+    const EncState S0   = S;
+    SpecCarry      C    = spec_begin(S);
+    uint32_t       mx   = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t s = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const uint32_t m = encode_symbol_spec<FIXUP, CB32>(S, C, tab[s], tab[s + 1], c, rc, sh, wdst);
+        mx               = m > mx ? m : mx;
+    }
+    spec_end(S, C);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > 32u) != 0, 0)) {
+        S = S0;
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) {
+            const uint32_t s = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            encode_symbol<FIXUP>(S, tab[s], tab[s + 1], c, rc, sh, false, wdst, 0xFFFFFFFFu);
+        }
+    }
+}
+
+template <bool FIXUP, bool CB32>
 __global__ void __launch_bounds__(64) k_encode_static(StaticEncArgs a)
 {
     __shared__ uint32_t tab[kStaticEntries + 2];
@@ -86,18 +115,23 @@ __global__ void __launch_bounds__(64) k_encode_static(StaticEncArgs a)
     // chunk, the next one in flight while this one is coded; all 64 lanes active
     const uint32_t minlen = __builtin_amdgcn_readfirstlane(wave_min(live ? len : 0xFFFFFFFFu));
     if (a.aligned16 && minlen != 0xFFFFFFFFu && minlen >= 32) {
-        const uint32_t main_end = (minlen & ~15u) - 16;
-        const uint4   *s16      = reinterpret_cast<const uint4 *>(src);
-        uint4          cur      = s16[0];
+        const uint32_t main_end = minlen & ~15u;
+        // every lane reads its block one whole 128-byte line at a time (ChunkQueue, redux_encode.hpp):
+        // with 16 bytes per visit the line is evicted between visits and fetched eight times
+        ChunkQueue Q;
+        Q.init(a.in + blk0 * (uint64_t)a.block_size, live ? lane * a.block_size : 0u, main_end);
+        constexpr uint32_t kChunkBudget = 16 * 4 + 32; // bytes a chunk may add without a per-store check
         for (; p < main_end; p += 16) {
-            const uint4    nxt  = s16[(p >> 4) + 1];
-            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const uint32_t s = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                encode_symbol<FIXUP>(S, tab[s], tab[s + 1], c, rc, sh, false, wdst, limit);
-            }
-            cur = nxt;
+            const uint4 cur = Q.pop();
+            if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit)) { // a slot is nearly full: every store checked
+                const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll 1
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t s = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                    encode_symbol<FIXUP>(S, tab[s], tab[s + 1], c, rc, sh, false, wdst, limit);
+                }
+            } else
+                static_chunk<FIXUP, CB32>(S, tab, cur, c, rc, sh, wdst);
         }
     }
     for (; p <= maxlen; p++) {
