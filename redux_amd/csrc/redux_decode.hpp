@@ -739,7 +739,11 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
                 const uint32_t j     = (uint32_t)__builtin_clz(~t2);
                 const uint32_t n     = k + j;
                 const uint32_t cons2 = S.consumed + n;
-                const uint32_t e     = f.eofq | k | (S.sbits - cons2); // sbits is 0 for a finished lane, cons2 > 0
+                // sbits is 0 for a finished lane, cons2 > 0.  Codes narrower than 32 bits: low == high shows
+                // as k == code_bits (the padding below the code differs), not as v_ffbh's -1, and the
+                // commit below takes the bit that survives the E3 steps from W alone, which is only
+                // right for k < code_bits: such a step goes to the careful commit as well.
+                const uint32_t e     = CB32 ? (f.eofq | k | (S.sbits - cons2)) : (f.eofq | (cb - 1u - k) | (S.sbits - cons2));
                 DEC_STAMP(5, e)
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)e < 0) == 0, 1)) {
                     dec_update(lds, A, T, f.s);

@@ -459,6 +459,31 @@ def test_static_model_errors(rx):
     assert torch.equal(d_out[4096:8192], d_in[4096:8192])
 
 
+def test_decode_full_wave_interval_collapse_narrow_codes(rx):
+    """Found by tools/soak_encode.py: with 16-bit codes the interval can collapse to low == high
+    (here at symbol 12443 of the block: range 1, all 16 bits shift out).  For codes narrower than
+    32 bits that shows as k == code_bits, which the lock-step decoder's unpredicated commit must
+    hand to the careful one -- and it only takes the unpredicated commit when all 64 lanes of a
+    wave are live, so the wave has to be full."""
+    import torch
+    blk = np.load(os.path.join(GOLDEN, "soak_block_8_14_16.npy"))
+    P = (8, 14, 16)
+    want, _ = ox.compress(blk.tobytes(), P, cap=200000)
+    for nrep in (64, 67):
+        host = np.tile(blk, nrep)
+        d_in = torch.from_numpy(host).cuda()
+        enc = rx.DeviceEncoder(P, 65536, host.size)
+        out, offs, _, summ = enc.encode(d_in)
+        torch.cuda.synchronize()
+        assert summ.tolist() == [0, 0]
+        assert out[: int(offs[1])].cpu().numpy().tobytes() == want
+        dec = rx.DeviceDecoder(P, 65536, nrep)
+        d_out, d_sizes, d_status, d_sum = dec.decode(out[: int(offs[nrep])], offs)
+        torch.cuda.synchronize()
+        assert d_sum.tolist() == [0, 0]
+        assert torch.equal(d_out, d_in)
+
+
 def test_dense_output_too_small_is_reported_not_overrun(rx):
     import ctypes as C
     import torch
