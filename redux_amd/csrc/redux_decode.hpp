@@ -186,9 +186,6 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
             }
             if (is_eof) { // codec.rs:136-138: returns before any renormalisation
                 done = true;
-            } else if (p >= capn) {
-                st   = REDUX_OUTPUT_TOO_SMALL;
-                done = true;
             } else {
                 const double   Y     = __builtin_fma((double)R1, rc, rc);
                 const uint32_t nlow  = low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
@@ -205,6 +202,9 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
                 consumed += n;
                 if (consumed > stream_bits) { // read_bits would hit Err(Eof) (bitio/mod.rs:107)
                     st   = REDUX_EOF;
+                    done = true;
+                } else if (p >= capn) { // the symbol is decoded; writing it is what fails (codec.rs:171)
+                    st   = REDUX_OUTPUT_TOO_SMALL;
                     done = true;
                 } else {
                     // k E1/E2 steps shift the value left (codec.rs:143-146 + :155-157); each of
@@ -439,13 +439,6 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
         S.n_out = p;
         return;
     }
-    if (!room) {
-        S.st    = REDUX_OUTPUT_TOO_SMALL;
-        S.dflag = 0x80000000u;
-        S.sbits = 0;
-        S.n_out = p;
-        return;
-    }
     if (may_update)
         dec_update(lds, A, T, f.s);
     const double   Y      = __builtin_fma(R1d, rc, rc);
@@ -463,6 +456,16 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
     S.consumed += n;
     if (S.consumed > stream_bits) { // read_bits would return Err(Eof) (bitio/mod.rs:107)
         S.st    = REDUX_EOF;
+        S.dflag = 0x80000000u;
+        S.sbits = 0;
+        S.n_out = p;
+        return;
+    }
+    // decompress_symbol (codec.rs:123-161) has returned the symbol; only now does decompress_stream
+    // try to write it (codec.rs:171), so a stream that runs dry in this symbol's renormalisation is
+    // Err(Eof) even when the block is full as well
+    if (!room) {
+        S.st    = REDUX_OUTPUT_TOO_SMALL;
         S.dflag = 0x80000000u;
         S.sbits = 0;
         S.n_out = p;

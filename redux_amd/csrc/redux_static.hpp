@@ -229,11 +229,6 @@ __global__ void __launch_bounds__(64) k_decode_static(StaticDecArgs a)
             done = true;
             continue;
         }
-        if (p >= capn) {
-            st   = REDUX_OUTPUT_TOO_SMALL;
-            done = true;
-            continue;
-        }
         const uint32_t lo = tab[s], hi = tab[s + 1];
         const double   Y     = __builtin_fma((double)R1, rc, rc);
         const uint32_t nlow  = low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
@@ -250,6 +245,11 @@ __global__ void __launch_bounds__(64) k_decode_static(StaticDecArgs a)
         consumed += n;
         if (consumed > stream_bits) { // read_bits would hit Err(Eof) (bitio/mod.rs:107)
             st   = REDUX_EOF;
+            done = true;
+            continue;
+        }
+        if (p >= capn) { // the symbol is decoded; writing it is what fails (codec.rs:171)
+            st   = REDUX_OUTPUT_TOO_SMALL;
             done = true;
             continue;
         }

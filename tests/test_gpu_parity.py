@@ -484,6 +484,22 @@ def test_decode_full_wave_interval_collapse_narrow_codes(rx):
         assert torch.equal(d_out, d_in)
 
 
+def test_eof_is_decided_before_the_capacity_error(rx):
+    """Found by tools/soak_decode.py: a damaged stream that fills the block AND runs dry inside the
+    renormalisation of the next symbol.  decompress_symbol (codec.rs:123-161) fails with Eof before
+    decompress_stream gets to write the symbol (codec.rs:171), so the status is Eof, not the
+    capacity error -- alone in a wave (careful commit only) and in a full wave."""
+    stream = np.load(os.path.join(GOLDEN, "soak_stream_8_16_32_eof_at_capacity.npy")).tobytes()
+    P, cap = (8, 16, 32), 8192
+    st, want = _oracle_decode_raw(stream, cap, P)
+    assert st == 1 and len(want) == cap
+    for nrep in (1, 64):
+        offs = np.arange(nrep + 1, dtype=np.uint64) * len(stream)
+        dec, sizes, status = rx.decompress_blocks(np.frombuffer(stream * nrep, dtype=np.uint8), offs, cap, P, check=False)
+        assert status.tolist() == [1] * nrep and sizes.tolist() == [cap] * nrep
+        assert dec[:cap].tobytes() == want and dec[(nrep - 1) * cap:].tobytes() == want
+
+
 def test_dense_output_too_small_is_reported_not_overrun(rx):
     import ctypes as C
     import torch

@@ -2,7 +2,7 @@
 """Soak (GPU box): many randomly shaped inputs through the device encoder + decoder, EVERY block compared
 with the CPU oracle (16 host threads).  Looks for rare-path bugs: the speculative coder half and its redo,
 long pending runs, freeze crossings at small freq_bits, ragged tails, dead lanes.
-usage: tools/soak_encode.py [seconds=120] [seed=1]"""
+usage: tools/soak_encode.py [seconds=120] [seed=1] [big]"""
 import os
 import sys
 import time
@@ -46,12 +46,13 @@ t_end = time.time() + budget
 it = blocks = 0
 while time.time() < t_end:
     params = WIDTHS[rng.integers(0, len(WIDTHS))]
-    bs = int(rng.choice([48, 1000, 4096, 16384, 65536]))
-    nb = int(rng.integers(1, 400)) if bs >= 16384 else int(rng.integers(1, 3000))
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"  # blocks beyond 64 KiB: u32 trees, the one-wave kernels
+    bs = int(rng.choice([100000, 131072, 262144, 70001])) if big else int(rng.choice([48, 1000, 4096, 16384, 65536]))
+    nb = int(rng.integers(1, 140)) if big else int(rng.integers(1, 400)) if bs >= 16384 else int(rng.integers(1, 3000))
     n = max(0, nb * bs - int(rng.integers(0, bs)))
     host = np.ascontiguousarray(make(n) if n else np.zeros(0, dtype=np.uint8))
     n = int(host.size)  # (a generator may return fewer bytes than asked)
-    want, wst = ox.compress_blocks(host, bs, params, nthreads=16, slot=bs * 5 + 1024)
+    want, wst = ox.compress_blocks(host, bs, params, nthreads=16, slot=bs * 5 + 1024)  # (8,10,32) frozen: up to 12 bits/symbol
     assert (wst == 0).all()
     d_in = torch.from_numpy(np.ascontiguousarray(host)).cuda()
     enc = rx.DeviceEncoder(params, bs, max(n, 1))
