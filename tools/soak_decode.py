@@ -33,7 +33,7 @@ it = blocks = damaged = 0
 seen = {}
 while time.time() < t_end:
     params = [(8, 30, 32), (8, 22, 24), (8, 14, 16), (8, 16, 32)][rng.integers(0, 4)]
-    bs = int(rng.choice([1024, 4096, 8192]))
+    bs = int(rng.choice([1024, 4096, 8192, 8192, 20000, 65536]))  # the long ones cross the freeze point of the narrow widths
     nb = int(rng.choice([64, 128, 64 + int(rng.integers(1, 64))]))
     alpha = rng.uniform(0.0, 2.5)
     w = 1.0 / np.arange(1, 257) ** alpha
