@@ -500,6 +500,43 @@ def test_eof_is_decided_before_the_capacity_error(rx):
         assert dec[:cap].tobytes() == want and dec[(nrep - 1) * cap:].tobytes() == want
 
 
+def test_device_entry_points_capture_into_a_hip_graph(rx):
+    """The _dev entry points only enqueue work on the caller's stream (no allocation, no
+    synchronisation), so an encode + decode pass can be captured once and replayed as a hipGraph
+    on new input bytes in the same buffers."""
+    import torch
+    nblocks = 300
+    n = nblocks * BLOCK - 1234
+    d_in = rx.gen_zipf(n, seed=1)
+    enc = rx.DeviceEncoder((8, 30, 32), BLOCK, n)
+    dec = rx.DeviceDecoder((8, 30, 32), BLOCK, nblocks)
+    enc.encode(d_in)  # warm-up outside the capture (code objects, torch's allocator)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            enc.encode_slots(d_in)
+            enc.compact(n)
+    torch.cuda.current_stream().wait_stream(side)
+    for seed in (2, 3):
+        rx.gen_zipf(n, seed=seed, out=d_in)      # new bytes, same buffer
+        enc.summary.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert enc.summary.tolist() == [0, 0]
+        offs = enc.offsets[: nblocks + 1]
+        total = int(offs[nblocks])
+        host = d_in.cpu().numpy()
+        for b in (0, 63, 64, nblocks - 1):
+            want, _ = ox.compress(host[b * BLOCK:(b + 1) * BLOCK].tobytes(), (8, 30, 32))
+            assert enc.out[int(offs[b]): int(offs[b + 1])].cpu().numpy().tobytes() == want, (seed, b)
+        d_out, d_sizes, d_status, d_sum = dec.decode(enc.out[:total], offs)
+        torch.cuda.synchronize()
+        assert d_sum.tolist() == [0, 0] and torch.equal(d_out[:n], d_in)
+
+
 def test_dense_output_too_small_is_reported_not_overrun(rx):
     import ctypes as C
     import torch
