@@ -556,6 +556,43 @@ def test_dense_output_too_small_is_reported_not_overrun(rx):
     assert bool((small[3 * BLOCK:] == 0xAB).all())
 
 
+@pytest.mark.parametrize("params,bs", [((8, 30, 32), 4096), ((8, 30, 32), 1000), ((8, 14, 16), 4090), ((8, 30, 32), 37)])
+def test_decoder_stays_inside_its_blocks(rx, params, bs):
+    """Guard bands: streams that decode to more symbols than a block holds, garbage and intact ones,
+    in full waves (the staged 16-byte / 4-byte stores of the lock-step decoder) and with block
+    sizes that are not store-aligned.  Nothing is written behind the last block, and a block that
+    overflows or fails leaves every OTHER block's bytes exactly as an all-intact decode gives them."""
+    import torch
+    rnd = np.random.default_rng(bs)
+    nb = 130
+    host = rnd.integers(0, 4, nb * bs, dtype=np.uint8)           # compressible: short streams
+    long_src = rnd.integers(0, 4, 3 * bs, dtype=np.uint8)        # one stream of 3 blocks' worth of symbols
+    out, offs, _ = rx.compress_blocks(host, bs, params)
+    streams = [out[int(offs[b]): int(offs[b + 1])].tobytes() for b in range(nb)]
+    too_long, _ = ox.compress(long_src.tobytes(), params)
+    bad = {5: too_long, 64: too_long, 70: rnd.integers(0, 256, 600, dtype=np.uint8).tobytes(), 129: too_long, 100: b""}
+    mixed = [bad.get(b, streams[b]) for b in range(nb)]
+    offs2 = np.zeros(nb + 1, dtype=np.int64)
+    offs2[1:] = np.cumsum([len(x) for x in mixed])
+    d_streams = torch.from_numpy(np.frombuffer(b"".join(mixed), dtype=np.uint8).copy()).cuda()
+    d_offs = torch.from_numpy(offs2).cuda()
+    dec = rx.DeviceDecoder(params, bs, nb)
+    big = torch.full((nb * bs + 4096,), 0xAB, dtype=torch.uint8, device="cuda:0")
+    dec.out = big[: nb * bs]
+    d_out, d_sizes, d_status, d_sum = dec.decode(d_streams, d_offs)
+    torch.cuda.synchronize()
+    assert bool((big[nb * bs:] == 0xAB).all())                    # nothing behind the last block
+    got = d_out.cpu().numpy()
+    st = d_status.cpu().numpy()
+    assert st[5] == 4 and st[64] == 4 and st[129] == 4 and st[100] != 0
+    for b in range(nb):
+        if b not in bad:
+            assert st[b] == 0 and int(d_sizes[b]) == bs
+            assert (got[b * bs:(b + 1) * bs] == host[b * bs:(b + 1) * bs]).all(), b
+    for b in (5, 64, 129):                                         # a full block of the long stream's symbols
+        assert int(d_sizes[b]) == bs and (got[b * bs:(b + 1) * bs] == long_src[:bs]).all(), b
+
+
 def test_cpp_host_mirror_end_to_end(rx, tmp_path):
     """The C++ mirror of the reference API (redux_amd/host/redux.hpp) through the C ABI on the GPU:
     doc-test, corpus round trip at three widths, Eof on a truncated stream."""
