@@ -344,7 +344,10 @@ static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *
     sa.offsets = (uint64_t *)d_out_offsets;
     sa.summary = (int32_t *)d_summary;
     sa.nblocks = g.nblocks;
-    k_scan_sizes<<<1, 1024, 0, s>>>(sa);
+    if (scan_is_coalesced(sa))
+        k_scan_sizes_coalesced<<<1, 1024, 0, s>>>(sa);
+    else
+        k_scan_sizes<<<1, 1024, 0, s>>>(sa);
 
     CompactArgs ca;
     ca.slots      = ws + g.off_slots;

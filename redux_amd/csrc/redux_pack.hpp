@@ -1,7 +1,8 @@
 // redux_pack.hpp -- what turns per-block slots into the dense stream (gfx950 only).
 //
 //   k_summarize      first failing status + number of failing blocks
-//   k_scan_sizes     sizes -> offsets (exclusive scan, one workgroup) + status summary
+//   k_scan_sizes     sizes -> offsets (exclusive scan, one workgroup) + status summary;
+//                    k_scan_sizes_coalesced for whole chunks of 4096 blocks (the headline shape)
 //   k_compact        slot b [0, size_b) -> out + offsets[b], 16-byte stores with byte realignment
 //   k_compact_rows   the same from row-major group areas (-DREDUX_ROWS=1 builds)
 //
@@ -44,6 +45,99 @@ struct ScanArgs {
     int32_t        *summary; // may be null: [first bad status, #bad]
     uint64_t        nblocks;
 };
+
+#ifndef REDUX_SCAN_COALESCED
+#define REDUX_SCAN_COALESCED 1
+#endif
+static inline bool scan_is_coalesced(const ScanArgs &a)
+{
+    return REDUX_SCAN_COALESCED && a.nblocks % 4096 == 0 && a.nblocks / 4096 <= 16 &&
+           ((((uintptr_t)a.sizes) | ((uintptr_t)a.status) | ((uintptr_t)a.offsets)) & 15) == 0;
+}
+
+// sizes -> offsets for whole chunks of 4096 blocks, at most sixteen of them (the 65,536-block
+// configuration): see scan_is_coalesced() for when the host picks this kernel.
+__global__ void __launch_bounds__(1024) k_scan_sizes_coalesced(ScanArgs a)
+{
+    __shared__ uint32_t bad_cnt;
+    __shared__ uint64_t bad_first; // (index << 8) | status, minimised
+    __shared__ uint64_t wtot[2][16];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        bad_cnt   = 0;
+        bad_first = ~0ull;
+    }
+    // Thread t takes quad t of every chunk, so a wave's loads and stores are contiguous (1 KiB of
+    // sizes, 2 KiB of offsets per instruction); all size loads are issued up front, then one wave
+    // scan and one barrier per chunk.  (k_scan_sizes' per-thread contiguous ranges cost 64
+    // different lines per load, and its two 64-register arrays spill: 113 us against this.)
+    const uint32_t nch  = (uint32_t)(a.nblocks / 4096);
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint4   *s4   = reinterpret_cast<const uint4 *>(a.sizes);
+    const int4    *t4   = reinterpret_cast<const int4 *>(a.status);
+    uint4          sz[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        sz[i] = (uint32_t)i < nch ? s4[i * 1024 + tid] : make_uint4(0, 0, 0, 0);
+    int4     stc     = t4[tid]; // the statuses travel one chunk ahead (64 more registers would spill)
+    uint64_t running = 0;
+    uint32_t nb      = 0;
+    uint64_t fb      = ~0ull;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if ((uint32_t)i >= nch) // (uniform)
+            continue;
+        const int4 stv = stc;
+        if ((uint32_t)i + 1 < nch)
+            stc = t4[(i + 1) * 1024 + tid];
+        // inclusive scan over the wave in 32 bits: 256 sizes of one wave stay below 2^32 for any
+        // input that fits in memory; wave totals and everything above them are 64-bit
+        const uint32_t qs   = sz[i].x + sz[i].y + sz[i].z + sz[i].w;
+        uint32_t       incl = qs;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            incl += lane >= (uint32_t)o ? v : 0u;
+        }
+        if (lane == 63)
+            wtot[i & 1][wave] = incl;
+        __syncthreads(); // one barrier per chunk: wtot is double-buffered, and chunk i+2's writers have passed chunk i+1's barrier
+        uint64_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint64_t v = wtot[i & 1][w];
+            before += (uint32_t)w < wave ? v : 0;
+            total += v;
+        }
+        const uint64_t q  = (uint64_t)i * 1024 + tid;
+        const uint64_t o0 = running + before + (incl - qs);
+        const uint64_t o1 = o0 + sz[i].x, o2 = o1 + sz[i].y, o3 = o2 + sz[i].z;
+        ulonglong2    *op = reinterpret_cast<ulonglong2 *>(a.offsets + 4 * q);
+        op[0]             = make_ulonglong2(o0, o1);
+        op[1]             = make_ulonglong2(o2, o3);
+        running += total;
+        const int32_t st4[4] = {stv.x, stv.y, stv.z, stv.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (st4[k] != REDUX_OK) {
+                nb++;
+                const uint64_t cand = ((4 * q + k) << 8) | (uint32_t)st4[k];
+                fb                  = cand < fb ? cand : fb;
+            }
+    }
+    if (nb) {
+        atomicAdd(&bad_cnt, nb);
+        atomicMin((unsigned long long *)&bad_first, (unsigned long long)fb);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.offsets[a.nblocks] = running;
+        if (a.summary) {
+            a.summary[0] = bad_cnt ? (int32_t)(bad_first & 0xFF) : REDUX_OK;
+            a.summary[1] = (int32_t)bad_cnt;
+        }
+    }
+}
 
 __global__ void __launch_bounds__(1024) k_scan_sizes(ScanArgs a)
 {

@@ -537,6 +537,37 @@ def test_device_entry_points_capture_into_a_hip_graph(rx):
         assert d_sum.tolist() == [0, 0] and torch.equal(d_out[:n], d_in)
 
 
+@pytest.mark.parametrize("nblocks", [4096, 8192 + 4096, 5000])
+def test_scan_offsets_and_status_summary(rx, nblocks):
+    """sizes -> offsets + status summary, on the coalesced kernel (whole chunks of 4096 blocks) and
+    on the general one: offsets are the exclusive scan of the block sizes, and statuses planted
+    between the two phases come back as (first failing status, number of failing blocks)."""
+    import torch
+    bs = 64
+    n = nblocks * bs
+    d_in = rx.gen_zipf(n, seed=nblocks)
+    enc = rx.DeviceEncoder((8, 30, 32), bs, n)
+    enc.encode_slots(d_in)
+    enc.compact(n)
+    torch.cuda.synchronize()
+    offs = enc.offsets[: nblocks + 1].cpu().numpy()
+    assert enc.summary.tolist() == [0, 0] and offs[0] == 0
+    host = d_in.cpu().numpy()
+    sizes = np.diff(offs)
+    for b in (0, 1, 1023, 1024, 4095, nblocks - 1):
+        want, _ = ox.compress(host[b * bs:(b + 1) * bs].tobytes(), (8, 30, 32))
+        assert sizes[b] == len(want)
+        assert enc.out[int(offs[b]): int(offs[b + 1])].cpu().numpy().tobytes() == want
+    enc.encode_slots(d_in)
+    bad = sorted({nblocks - 1, 4095, 2000, 77})
+    enc.status[bad[1:]] = 3
+    enc.status[bad[0]] = 1   # the first failing block decides summary[0]
+    enc.compact(n)
+    torch.cuda.synchronize()
+    assert enc.summary.tolist() == [1, len(bad)]
+    assert (enc.offsets[: nblocks + 1].cpu().numpy() == offs).all()
+
+
 def test_dense_output_too_small_is_reported_not_overrun(rx):
     import ctypes as C
     import torch
