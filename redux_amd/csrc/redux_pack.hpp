@@ -75,11 +75,23 @@ __global__ void __launch_bounds__(1024) k_scan_sizes_coalesced(ScanArgs a)
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint4   *s4   = reinterpret_cast<const uint4 *>(a.sizes);
     const int4    *t4   = reinterpret_cast<const int4 *>(a.status);
-    uint4          sz[16];
+    // statuses first, packed to a byte each as they arrive (a status is 0..5), then the sizes: 16 + 64
+    // registers live in the loop instead of 128, and no load inside it
+    uint32_t stp[16];
+    {
+        int4 stv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            stv[i] = (uint32_t)i < nch ? t4[i * 1024 + tid] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            stp[i] = ((uint32_t)stv[i].x & 0xFFu) | (((uint32_t)stv[i].y & 0xFFu) << 8) | (((uint32_t)stv[i].z & 0xFFu) << 16) |
+                     ((uint32_t)stv[i].w << 24);
+    }
+    uint4 sz[16];
 #pragma unroll
     for (int i = 0; i < 16; i++)
         sz[i] = (uint32_t)i < nch ? s4[i * 1024 + tid] : make_uint4(0, 0, 0, 0);
-    int4     stc     = t4[tid]; // the statuses travel one chunk ahead (64 more registers would spill)
     uint64_t running = 0;
     uint32_t nb      = 0;
     uint64_t fb      = ~0ull;
@@ -87,9 +99,6 @@ __global__ void __launch_bounds__(1024) k_scan_sizes_coalesced(ScanArgs a)
     for (int i = 0; i < 16; i++) {
         if ((uint32_t)i >= nch) // (uniform)
             continue;
-        const int4 stv = stc;
-        if ((uint32_t)i + 1 < nch)
-            stc = t4[(i + 1) * 1024 + tid];
         // inclusive scan over the wave in 32 bits: 256 sizes of one wave stay below 2^32 for any
         // input that fits in memory; wave totals and everything above them are 64-bit
         const uint32_t qs   = sz[i].x + sz[i].y + sz[i].z + sz[i].w;
@@ -116,14 +125,17 @@ __global__ void __launch_bounds__(1024) k_scan_sizes_coalesced(ScanArgs a)
         op[0]             = make_ulonglong2(o0, o1);
         op[1]             = make_ulonglong2(o2, o3);
         running += total;
-        const int32_t st4[4] = {stv.x, stv.y, stv.z, stv.w};
+        if (stp[i] != 0) { // (rare) some block of this quad failed
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (st4[k] != REDUX_OK) {
-                nb++;
-                const uint64_t cand = ((4 * q + k) << 8) | (uint32_t)st4[k];
-                fb                  = cand < fb ? cand : fb;
+            for (int k = 0; k < 4; k++) {
+                const uint32_t st = (stp[i] >> (8 * k)) & 0xFFu;
+                if (st != REDUX_OK) {
+                    nb++;
+                    const uint64_t cand = ((4 * q + k) << 8) | st;
+                    fb                  = cand < fb ? cand : fb;
+                }
             }
+        }
     }
     if (nb) {
         atomicAdd(&bad_cnt, nb);
