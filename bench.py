@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: encode MB/s on BASELINE.json configs[1].
 
-  python bench.py --gpus N --steps K --warmup W          (N=1)
+  python bench.py --gpus N --steps K --warmup W          (any N: for N > 1 and no RANK in the
+                                                          environment it starts the N rank processes itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the hot path over one batch: every rank codes its own 65,536 blocks of
@@ -54,6 +55,28 @@ def host_cores():
     return n
 
 
+def launch_command(n, argv, port=None):
+    """The rank launcher `python bench.py --gpus N` turns into (one process per GPU over RCCL)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv, run=None):
+    """Starts the N rank processes as children, lets rank 0's JSON line through on stdout and
+    returns the launcher's exit code.  `run` is injectable for the CPU test."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only kind the host driver supports
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launch_command(n, argv)
+    return (run or subprocess.call)(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +94,12 @@ def main():
                          "(the line says so; not a scaling measurement)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Plain `python bench.py --gpus N`: this process becomes the launcher.  It has made no HIP
+        # call (torch is not even imported yet) and starts N fresh rank processes; it never
+        # re-execs itself.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
@@ -79,7 +108,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     if args.rehearse_on_one_gpu:
         local_rank = 0
@@ -142,13 +171,23 @@ def main():
     value = total_in / elapsed * args.steps / 1e6
     algo_bytes = n + out_bytes
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    import ctypes as C
+    from redux_amd import _lib
+    cp = _lib.Params(*PARAMS)
+    # the kernel the library's dispatch picked for exactly these arguments (not an assumption)
+    kname = _lib.lib().redux_encode_kernel_name(C.byref(cp), C.c_void_p(d_in.data_ptr()), n, BLOCK).decode()
+    dname = _lib.lib().redux_decode_kernel_name(C.byref(cp), BLOCK).decode()
+    # `traffic` is not measured by this run: it is the PMC figure of a separate rocprofv3 --pmc pass
+    # of this same command (tools/prof_traffic.sh), kept per workload in profiles/traffic.json
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload and tj.get("blocks") == nblocks:
-                traffic = tj.get("hbm_bytes_per_launch")
+            for ent in tj.get("entries", [tj]):
+                if ent.get("workload") == args.workload and ent.get("blocks") == nblocks and ent.get("kernel", "k_encode_pair") in kname:
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_src = ent.get("source", "profiles/traffic.json")
         except Exception:
             traffic = None
     line = {
@@ -176,12 +215,13 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_encode_pair<false, true> (u16 tree, model wave + coder wave, code_bits 32)",
+            "kernel": kname,
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
             "frac": round(achieved * 1e9 / HBM_PEAK, 5),
             "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_ms": round(kern_ms, 3),
         },
@@ -202,7 +242,7 @@ def main():
         torch.cuda.synchronize()
         assert d_sum.tolist() == [0, 0] and torch.equal(d_out, d_in), "decode(encode(x)) != x"
         dms = e0.elapsed_time(e1)
-        line["decode"] = {"kernel": "k_decode_lock (u16 tree, one wave per 64 blocks)", "ms": round(dms, 3),
+        line["decode"] = {"kernel": dname, "ms": round(dms, 3),
                           "MBps": round(n / (dms * 1e-3) / 1e6, 1),
                           "algorithmic_GBps": round(algo_bytes / (dms * 1e-3) / 1e9, 2), "roundtrip_equal": True}
 

@@ -117,6 +117,9 @@ def _params_of(model_or_params):
     raise TypeError("expected Parameters, AdaptiveTreeModel or a (symbol, frequency, code) triple")
 
 
+MAX_BLOCK_BYTES = 0xFFFFFF00  # largest single block / whole stream the C ABI takes (redux_compress)
+
+
 def version():
     return _lib.lib().redux_version().decode()
 
@@ -197,10 +200,21 @@ def decompress(istream, ostream, model, max_output=None):
     L = _lib.lib()
     cp = P._c()
     _raise(L.redux_device_supports(C.byref(cp)))
+    # The reference writes to an unbounded io::Write (src/lib.rs:113); the C ABI wants a capacity.
+    # With no explicit max_output the capacity grows until the stream fits (or the ABI's one-block
+    # limit of 0xFFFFFF00 bytes is reached): a highly compressible stream (2 MiB of zeros is
+    # ~500 bytes) must not fail because of a guess.
     cap = max_output if max_output is not None else max(64 * len(a), 1 << 20)
-    out = np.empty(cap, dtype=np.uint8)
-    bi, bo = C.c_uint64(), C.c_uint64()
-    _raise(L.redux_decompress(C.byref(cp), _ptr(a), len(a), out.ctypes.data, cap, C.byref(bi), C.byref(bo)))
+    while True:
+        cap = min(cap, MAX_BLOCK_BYTES)
+        out = np.empty(cap, dtype=np.uint8)
+        bi, bo = C.c_uint64(), C.c_uint64()
+        st = L.redux_decompress(C.byref(cp), _ptr(a), len(a), out.ctypes.data, cap, C.byref(bi), C.byref(bo))
+        if st == _lib.OUTPUT_TOO_SMALL and max_output is None and cap < MAX_BLOCK_BYTES:
+            cap *= 8
+            continue
+        _raise(st)
+        break
     ostream.write(out[: bo.value].tobytes())
     return (bi.value, bo.value)
 
@@ -215,6 +229,20 @@ def _torch():
 
 def _stream_ptr(torch):
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _on_device(method):
+    """The C ABI launches on HIP's CURRENT device and on the stream it is handed.  A coder object
+    built for cuda:1 while cuda:0 is current would run its kernels on GPU 0 against GPU 1's memory,
+    so every launching method makes the object's device current first (torch's current stream of
+    that device is then the one passed down)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with _torch().cuda.device(self.device):
+            return method(self, *args, **kwargs)
+    return wrapper
 
 
 class DeviceEncoder:
@@ -244,6 +272,7 @@ class DeviceEncoder:
     def _ws_ptr(self):
         return C.c_void_p(self.ws.data_ptr() + self.ws_off)
 
+    @_on_device
     def encode_slots(self, d_in):
         """Phase 1 only: the coder kernel (padded slots + sizes inside the workspace)."""
         torch = _torch()
@@ -254,6 +283,7 @@ class DeviceEncoder:
                                                _stream_ptr(torch))
         _raise(st)
 
+    @_on_device
     def compact(self, n):
         """Phase 2 only: scan + gather into the dense output."""
         torch = _torch()
@@ -265,6 +295,7 @@ class DeviceEncoder:
                                                 _stream_ptr(torch))
         _raise(st)
 
+    @_on_device
     def encode(self, d_in):
         """Full pass, stream-ordered: returns (out, offsets[nblocks+1], status, summary) views
         of this encoder's buffers (valid until the next call)."""
@@ -302,6 +333,7 @@ class DeviceDecoder:
         self.status = torch.zeros(self.max_blocks, dtype=torch.int32, device=self.device)
         self.summary = torch.zeros(2, dtype=torch.int32, device=self.device)
 
+    @_on_device
     def decode(self, d_streams, d_offsets):
         torch = _torch()
         nb = d_offsets.numel() - 1
@@ -344,6 +376,7 @@ class DeviceStaticCoder:
         self.summary = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.dec_out = None
 
+    @_on_device
     def encode(self, d_in):
         torch = _torch()
         n = d_in.numel()
@@ -358,6 +391,7 @@ class DeviceStaticCoder:
         nb = _lib.lib().redux_block_count(n, self.block_size)
         return self.out, self.offsets[: nb + 1], self.status[:nb], self.summary
 
+    @_on_device
     def decode(self, d_streams, d_offsets):
         torch = _torch()
         nb = d_offsets.numel() - 1
@@ -381,14 +415,16 @@ class DeviceStaticCoder:
 def gen_iid(nbytes, seed=0x5EED0001, first_byte=0, device="cuda:0", out=None):
     torch = _torch()
     t = out if out is not None else torch.empty(nbytes, dtype=torch.uint8, device=device)
-    _raise(_lib.lib().redux_gen_iid_dev(C.c_void_p(t.data_ptr()), nbytes, first_byte, seed, _stream_ptr(torch)))
+    with torch.cuda.device(t.device):
+        _raise(_lib.lib().redux_gen_iid_dev(C.c_void_p(t.data_ptr()), nbytes, first_byte, seed, _stream_ptr(torch)))
     return t
 
 
 def gen_zipf(nbytes, seed=0x5EED0005, first_byte=0, device="cuda:0", out=None):
     torch = _torch()
     t = out if out is not None else torch.empty(nbytes, dtype=torch.uint8, device=device)
-    _raise(_lib.lib().redux_gen_zipf_dev(C.c_void_p(t.data_ptr()), nbytes, first_byte, seed, _stream_ptr(torch)))
+    with torch.cuda.device(t.device):
+        _raise(_lib.lib().redux_gen_zipf_dev(C.c_void_p(t.data_ptr()), nbytes, first_byte, seed, _stream_ptr(torch)))
     return t
 
 

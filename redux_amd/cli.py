@@ -36,7 +36,7 @@ def parse(argv):
                     opts["block_size"] = int(val)
                 except ValueError:
                     return None
-                if opts["block_size"] < 0:
+                if not 0 <= opts["block_size"] <= (1 << 30):  # container.MAX_BLOCK_SIZE: a usage error, not a traceback
                     return None
         else:
             return None
@@ -73,7 +73,16 @@ def main(argv=None):
                 i_n, o_n = len(data), len(blob)
             print("Compressed %d bytes into %d bytes, ratio: %.3f" % (i_n, o_n, i_n / o_n), file=sys.stderr)
         else:
+            # A container is recognised by a well-formed HEADER, not by its magic alone: a raw
+            # reference stream may begin with the same four bytes.
+            is_container = False
             if data[:4] == container.MAGIC:
+                try:
+                    container.unpack(data)
+                    is_container = True
+                except api.Error:
+                    is_container = False
+            if is_container:
                 out = container.decompress_bytes(data)
                 sink.write(out)
                 i_n, o_n = len(data), len(out)

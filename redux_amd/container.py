@@ -24,6 +24,10 @@ from . import api
 MAGIC = b"RDXB"
 VERSION = 1
 HEADER = struct.Struct("<4sBBBBIIQQ")
+# A header field, not a promise: a crafted 40-byte file must not make the decoder allocate
+# gigabytes.  The container never holds blocks above 1 GiB (the CLI refuses larger ones), and
+# the decode capacity is additionally capped by the total length the header declares.
+MAX_BLOCK_SIZE = 1 << 30
 
 
 def pack(streams, offsets, params, block_size, total_len):
@@ -44,7 +48,7 @@ def unpack(buf):
     if len(b) < HEADER.size:
         raise api.Eof()
     magic, ver, sb, fb, cb, block_size, _res, nblocks, total = HEADER.unpack_from(b, 0)
-    if magic != MAGIC or ver != VERSION or block_size == 0:
+    if magic != MAGIC or ver != VERSION or block_size == 0 or block_size > MAX_BLOCK_SIZE:
         raise api.InvalidInput()
     P = api.Parameters(sb, fb, cb)
     if nblocks != (1 if total == 0 else (total + block_size - 1) // block_size):
@@ -63,6 +67,8 @@ def unpack(buf):
 
 def compress_bytes(data, block_size=65536, params=(8, 30, 32)):
     """bytes -> container bytes (every block coded on the GPU)."""
+    if not 0 < block_size <= MAX_BLOCK_SIZE:
+        raise api.InvalidInput()
     out, offs, _ = api.compress_blocks(data, block_size, params)
     return pack(out, offs, params, block_size, len(data))
 
@@ -70,11 +76,17 @@ def compress_bytes(data, block_size=65536, params=(8, 30, 32)):
 def decompress_bytes(buf):
     """container bytes -> original bytes."""
     P, block_size, total, offsets, payload = unpack(buf)
-    out, sizes, _ = api.decompress_blocks(payload, offsets, block_size, P)
-    nb = len(sizes)
+    # A stream of s bytes can decode to far more than s bytes (64 KiB of one symbol is ~400 bytes),
+    # so only the declared total bounds the capacity; but every block's stream has at least one
+    # byte, so a header that declares more blocks than there are payload bytes is malformed.
+    nb = len(offsets) - 1
+    if len(payload) < nb:
+        raise api.InvalidInput()
+    cap = max(1, min(block_size, total))  # one short block never needs block_size bytes of capacity
+    out, sizes, _ = api.decompress_blocks(payload, offsets, cap, P)
     expect = [min(block_size, total - b * block_size) for b in range(nb)] if total else [0]
     if [int(x) for x in sizes] != expect:
         raise api.InvalidInput()
-    if total == nb * block_size:
+    if total == nb * cap:
         return out.tobytes()
-    return b"".join(out[b * block_size: b * block_size + int(sizes[b])].tobytes() for b in range(nb))
+    return b"".join(out[b * cap: b * cap + int(sizes[b])].tobytes() for b in range(nb))

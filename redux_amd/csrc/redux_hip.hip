@@ -202,13 +202,92 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
         }                                                                                              \
     } while (0)
 
+// ---- which kernel a call runs: ONE decision, used by the launch code and reported by
+// redux_encode_kernel_name / redux_decode_kernel_name (bench.py's roofline.kernel) ------------
+enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Any };
+enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Any };
+
+// 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset; otherwise
+// (giant blocks, whole-stream mode) one block per wave.
+static uint32_t encode_lanes(const Geometry &g, uint32_t block_size)
+{
+    return (64ull * g.slot_bytes < (1ull << 32) && 64ull * block_size < (1ull << 32)) ? 64u : 1u;
+}
+
+static EncKernel pick_encode_kernel(const Geometry &g, const redux_params *p, bool aligned16, uint32_t block_size)
+{
+    if (g.any)
+        return EncKernel::Any;
+    bool pair = g.u16 && aligned16 && encode_lanes(g, block_size) == 64;
+#ifdef REDUX_AB // A/B timing builds only: REDUX_ENCODE_KERNEL=single pins the one-wave kernel
+    const char *force = getenv("REDUX_ENCODE_KERNEL");
+    if (force && !strcmp(force, "single"))
+        pair = false;
+#endif
+    // (a u16 tree means blocks of <= 65536 symbols, so count < 2^17: the pair kernel never needs FIXUP)
+    if (pair && !g.fixup)
+        return p->code_bits == 32 ? EncKernel::PairCb32 : EncKernel::Pair;
+    if (g.u16)
+        return g.fixup ? EncKernel::SingleU16Fixup : EncKernel::SingleU16;
+    return EncKernel::SingleU32;
+}
+
+static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p)
+{
+    if (g.any)
+        return DecKernel::Any;
+    bool lock = g.u16 && !g.fixup;
+#ifdef REDUX_AB // A/B timing builds only: REDUX_DECODE_KERNEL=generic pins k_decode
+    if (getenv("REDUX_DECODE_KERNEL"))
+        lock = false;
+#endif
+    if (lock)
+        return p->code_bits == 32 ? DecKernel::LockCb32 : DecKernel::Lock;
+    if (g.u16)
+        return g.fixup ? DecKernel::GenericU16Fixup : DecKernel::GenericU16;
+    return DecKernel::GenericU32;
+}
+
 } // namespace redux
 
 using namespace redux;
 
 extern "C" {
 
-const char *redux_version(void) { return "redux_hip 0.1.0 gfx950"; }
+const char *redux_version(void) { return "redux_hip 0.2.0 gfx950"; }
+
+const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size)
+{
+    if (check_params(p) != REDUX_OK || block_size == 0)
+        return "";
+    const Geometry g = geometry(p, in_len, block_size);
+    const bool aligned16 = (((uintptr_t)d_in) & 15) == 0 && (block_size & 15) == 0;
+    switch (pick_encode_kernel(g, p, aligned16, block_size)) {
+    case EncKernel::PairCb32: return "k_encode_pair<false, true> (u16 tree, model wave + coder wave, code_bits 32)";
+    case EncKernel::Pair: return "k_encode_pair<false, false> (u16 tree, model wave + coder wave)";
+    case EncKernel::SingleU16: return "k_encode<true, false> (u16 tree, one wave per 64 blocks)";
+    case EncKernel::SingleU16Fixup: return "k_encode<true, true> (u16 tree, one wave per 64 blocks, quotient fix-up)";
+    case EncKernel::SingleU32: return "k_encode<false, true> (u32 tree)";
+    case EncKernel::Any: return "k_encode_any (general parameters, one lane per block)";
+    }
+    return "";
+}
+
+const char *redux_decode_kernel_name(const redux_params *p, uint32_t block_size)
+{
+    if (check_params(p) != REDUX_OK || block_size == 0)
+        return "";
+    const Geometry g = geometry(p, block_size, block_size);
+    switch (pick_decode_kernel(g, p)) {
+    case DecKernel::LockCb32: return "k_decode_lock<true> (u16 tree, one wave per 64 blocks, code_bits 32)";
+    case DecKernel::Lock: return "k_decode_lock<false> (u16 tree, one wave per 64 blocks)";
+    case DecKernel::GenericU16: return "k_decode<true, false> (u16 tree, per-lane control flow)";
+    case DecKernel::GenericU16Fixup: return "k_decode<true, true> (u16 tree, quotient fix-up)";
+    case DecKernel::GenericU32: return "k_decode<false, true> (u32 tree)";
+    case DecKernel::Any: return "k_decode_any (general parameters, one lane per block)";
+    }
+    return "";
+}
 
 int redux_params_check(uint32_t symbol, uint32_t frequency, uint32_t code) /* model/mod.rs:64 */
 {
@@ -303,26 +382,21 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     a.claims     = (uint32_t *)(ws + g.off_mode + 256);
     // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset;
     // otherwise (giant blocks, whole-stream mode) one block per wave.
-    a.lanes = (64ull * g.slot_bytes < (1ull << 32) && 64ull * block_size < (1ull << 32)) ? 64u : 1u;
+    a.lanes = encode_lanes(g, block_size);
     const uint32_t grid = (uint32_t)((g.nblocks + a.lanes - 1) / a.lanes);
-    // REDUX_ENCODE_KERNEL=single pins the one-wave kernel (A/B timing only)
-    const char *force = getenv("REDUX_ENCODE_KERNEL");
-    const bool  pair  = g.u16 && a.aligned16 && a.lanes == 64 && !(force && !strcmp(force, "single"));
-    // (a u16 tree means blocks of <= 65536 symbols, so count < 2^17: the pair kernel never needs FIXUP)
+    const EncKernel which = pick_encode_kernel(g, p, a.aligned16 != 0, block_size);
     // what the pair kernel leaves in the slots (CompactArgs::mode): byte 0x01 -> row-major group
     // areas, 0x02 -> linear slots whose dwords are byte-reversed
-    if (pair && !g.fixup && (REDUX_ROWS || REDUX_PAIR_SWAP))
+    if ((which == EncKernel::PairCb32 || which == EncKernel::Pair) && (REDUX_ROWS || REDUX_PAIR_SWAP))
         HIP_TRY(hipMemsetAsync(ws + g.off_mode, REDUX_ROWS ? 1 : 2, 4, s));
-    if (pair && !g.fixup && p->code_bits == 32)
-        k_encode_pair<false, true><<<grid, 128, 0, s>>>(a);
-    else if (pair && !g.fixup)
-        k_encode_pair<false, false><<<grid, 128, 0, s>>>(a);
-    else if (g.u16 && !g.fixup)
-        k_encode<true, false><<<grid, 64, 0, s>>>(a);
-    else if (g.u16)
-        k_encode<true, true><<<grid, 64, 0, s>>>(a);
-    else
-        k_encode<false, true><<<grid, 64, 0, s>>>(a);
+    switch (which) {
+    case EncKernel::PairCb32: k_encode_pair<false, true><<<grid, 128, 0, s>>>(a); break;
+    case EncKernel::Pair: k_encode_pair<false, false><<<grid, 128, 0, s>>>(a); break;
+    case EncKernel::SingleU16: k_encode<true, false><<<grid, 64, 0, s>>>(a); break;
+    case EncKernel::SingleU16Fixup: k_encode<true, true><<<grid, 64, 0, s>>>(a); break;
+    case EncKernel::SingleU32: k_encode<false, true><<<grid, 64, 0, s>>>(a); break;
+    case EncKernel::Any: break; // handled above
+    }
     HIP_TRY(hipGetLastError());
     return REDUX_OK;
 }
@@ -527,17 +601,14 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         a.aligned4 = 2; // 16-byte aligned blocks: the lock-step decoder stages four dwords per store
     a.in_used    = (uint64_t *)d_in_used;
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
-    const char *force = getenv("REDUX_DECODE_KERNEL"); // "generic" pins k_decode (A/B timing only)
-    if (g.u16 && !g.fixup && !force && p->code_bits == 32)
-        k_decode_lock<true><<<grid, 64, 0, s>>>(a);
-    else if (g.u16 && !g.fixup && !force)
-        k_decode_lock<false><<<grid, 64, 0, s>>>(a);
-    else if (g.u16 && !g.fixup)
-        k_decode<true, false><<<grid, 64, 0, s>>>(a);
-    else if (g.u16)
-        k_decode<true, true><<<grid, 64, 0, s>>>(a);
-    else
-        k_decode<false, true><<<grid, 64, 0, s>>>(a);
+    switch (pick_decode_kernel(g, p)) {
+    case DecKernel::LockCb32: k_decode_lock<true><<<grid, 64, 0, s>>>(a); break;
+    case DecKernel::Lock: k_decode_lock<false><<<grid, 64, 0, s>>>(a); break;
+    case DecKernel::GenericU16: k_decode<true, false><<<grid, 64, 0, s>>>(a); break;
+    case DecKernel::GenericU16Fixup: k_decode<true, true><<<grid, 64, 0, s>>>(a); break;
+    case DecKernel::GenericU32: k_decode<false, true><<<grid, 64, 0, s>>>(a); break;
+    case DecKernel::Any: break; // handled above
+    }
     if (d_summary)
         k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
     HIP_TRY(hipGetLastError());

@@ -47,20 +47,31 @@ def encode_file_sharded(data, block_size, encode_local, device, group=None, root
     n = int(hdr.item())
     nblocks = block_count(n, block_size)
     ranges = shard_ranges(nblocks, world)
+    if n == 0:
+        # the empty input is ONE empty block (redux_block_count), and it belongs to the root
+        # whichever rank that is: nobody else codes anything
+        ranges = [(0, 1) if r == root else (0, 0) for r in range(world)]
     per = max(b1 - b0 for b0, b1 in ranges)
     # 1. scatter equal-size (padded) contiguous ranges
     mine = torch.empty(per * block_size, dtype=torch.uint8, device=device)
     if rank == root:
-        pad = torch.zeros(world * per * block_size, dtype=torch.uint8, device=device)
-        pad[:n] = data
-        chunks = list(pad.view(world, per * block_size).unbind(0))
+        # full ranges are views of the caller's tensor; only a ragged or empty range (at most the
+        # last two) gets a zero-padded copy, so the root holds the file once, not twice
+        span = per * block_size
+        chunks = []
+        for r in range(world):
+            lo, hi = min(n, r * span), min(n, (r + 1) * span)
+            if hi - lo == span:
+                chunks.append(data[lo:hi])
+            else:
+                c = torch.zeros(span, dtype=torch.uint8, device=device)
+                c[: hi - lo] = data[lo:hi]
+                chunks.append(c)
         dist.scatter(mine, chunks, src=root, group=group)
     else:
         dist.scatter(mine, None, src=root, group=group)
     b0, b1 = ranges[rank]
     my_bytes = max(0, min(n, b1 * block_size) - b0 * block_size) if b1 > b0 else 0
-    if n == 0 and rank == root:
-        b0, b1, my_bytes = 0, 1, 0  # the empty input is one empty block
     # 2. code this rank's range
     sizes = torch.zeros(per, dtype=torch.int64, device=device)
     if b1 > b0:
@@ -82,8 +93,6 @@ def encode_file_sharded(data, block_size, encode_local, device, group=None, root
         dist.gather(payload, recv, dst=root, group=group)
         dense = torch.cat([recv[r][: totals[r]] for r in range(world)])
         flat = torch.cat([all_sizes[r][: ranges[r][1] - ranges[r][0]] for r in range(world)])
-        if n == 0:
-            flat = all_sizes[root][:1]
         offsets = torch.zeros(flat.numel() + 1, dtype=torch.int64, device=device)
         offsets[1:] = torch.cumsum(flat, 0)
         return dense, offsets

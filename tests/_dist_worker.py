@@ -36,18 +36,18 @@ def oracle_decode_local(dense, offs, block_size):
     return out, sizes
 
 
-def worker(rank, world, port, path, block_size, result_path):
+def worker(rank, world, port, path, block_size, result_path, root=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         data = None
-        if rank == 0:
+        if rank == root:
             raw = open(path, "rb").read() if path else b""
             data = torch.frombuffer(bytearray(raw), dtype=torch.uint8) if raw else torch.empty(0, dtype=torch.uint8)
-        dense, offs = rd.encode_file_sharded(data, block_size, oracle_encode_local, "cpu")
-        back = rd.decode_file_sharded(dense, offs, block_size, oracle_decode_local, "cpu")
-        if rank == 0:
+        dense, offs = rd.encode_file_sharded(data, block_size, oracle_encode_local, "cpu", root=root)
+        back = rd.decode_file_sharded(dense, offs, block_size, oracle_decode_local, "cpu", root=root)
+        if rank == root:
             torch.save({"dense": dense, "offs": offs, "back": back}, result_path)
     finally:
         dist.destroy_process_group()

@@ -46,3 +46,19 @@ def test_cli_usage_and_open_errors(tmp_path, capsys):  # src/main.rs:84-106
     assert cli.main(["-c", "-i", str(src), "-o", str(tmp_path / "no_dir" / "out")]) == 2
     assert cli.parse(["-d", "-o", "o", "-i", "i", "--block-size", "65536"]) == \
         {"compress": False, "input": "i", "output": "o", "block_size": 65536}
+
+
+def test_unpack_rejects_oversized_block_size():
+    # a crafted 40-byte file must not be able to make the decoder allocate gigabytes
+    blob = container.HEADER.pack(container.MAGIC, container.VERSION, 8, 30, 32, 0xFFFFFFFF, 0, 1, 1) + b"\x01\0\0\0" + b"\xAA"
+    with pytest.raises(api.InvalidInput):
+        container.unpack(blob)
+    with pytest.raises(api.InvalidInput):
+        container.compress_bytes(b"abc", block_size=(1 << 30) + 1)
+
+
+def test_cli_block_size_range_is_a_usage_error():
+    assert cli.parse(["-c", "--block-size", str(1 << 33)]) is None   # used to be truncated by ctypes
+    assert cli.parse(["-c", "--block-size", "-1"]) is None
+    assert cli.parse(["-c", "--block-size", str(1 << 30)])["block_size"] == 1 << 30
+    assert cli.main(["-c", "--block-size", str(1 << 33)]) == 1

@@ -25,19 +25,21 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("key,block_size,world", [
-    ("canterbury/alice29.txt", 65536, 2),   # 3 blocks over 2 ranks: ragged ranges
-    ("canterbury/xargs.1", 65536, 2),       # 1 block: rank 1 gets nothing
-    ("calgary/paper1", 4096, 2),            # 13 blocks
-    (None, 65536, 2),                       # empty input: one empty block
+@pytest.mark.parametrize("key,block_size,world,root", [
+    ("canterbury/alice29.txt", 65536, 2, 0),   # 3 blocks over 2 ranks: ragged ranges
+    ("canterbury/xargs.1", 65536, 2, 0),       # 1 block: rank 1 gets nothing
+    ("calgary/paper1", 4096, 2, 0),            # 13 blocks
+    (None, 65536, 2, 0),                       # empty input: one empty block
+    (None, 65536, 2, 1),                       # ... owned by a root that is not rank 0
+    ("calgary/paper1", 4096, 2, 1),
 ])
-def test_sharded_encode_decode_matches_single_process(key, block_size, world, tmp_path):
+def test_sharded_encode_decode_matches_single_process(key, block_size, world, root, tmp_path):
     path = os.path.join(GOLDEN, "corpora", key) if key else None
     raw = open(path, "rb").read() if path else b""
     result = str(tmp_path / "root.pt")
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_dist_worker.worker, args=(r, world, port, path, block_size, result)) for r in range(world)]
+    procs = [ctx.Process(target=_dist_worker.worker, args=(r, world, port, path, block_size, result, root)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -774,3 +774,142 @@ def test_full_size_config_roundtrip(rx, kind):
     assert torch.equal(d_out, d_in)
     del dec, enc, d_in, d_out, out
     torch.cuda.empty_cache()
+
+
+def _splitmix(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _host_zipf(rx, first, n):
+    with np.errstate(over="ignore"):
+        j = np.arange(first, first + n, dtype=np.uint64)
+        u = (_splitmix(np.uint64(0x5EED0005) + j) >> np.uint64(32)).astype(np.uint32)
+    return np.searchsorted(rx.zipf_thresholds(), u, side="left").astype(np.uint8)
+
+
+def _host_iid(first, n):
+    with np.errstate(over="ignore"):
+        j = np.arange(first, first + n, dtype=np.uint64)
+        words = _splitmix(np.uint64(0x5EED0001) + (j >> np.uint64(3)))
+        return ((words >> ((j & np.uint64(7)) * np.uint64(8))) & np.uint64(0xFF)).astype(np.uint8)
+
+
+def test_config4_every_rank_shard_at_its_stated_offset(rx):
+    """BASELINE.json configs[4] at its STATED size: the 8 GiB Zipf(1.2) stream is 8 rank shards of
+    16,384 blocks, rank r owning stream bytes [r GiB, (r+1) GiB).  One GPU codes the eight shards
+    one after the other exactly as rank r would (`first_byte = r << 30`, so shards 4..7 lie beyond
+    4 GiB): the generator is checked against its host definition AT that offset, every shard is
+    encoded, decoded back on the device and compared, and blocks sampled across the shard are
+    compared byte for byte with the oracle."""
+    import torch
+    nblocks = 16384
+    n = nblocks * BLOCK
+    enc = rx.DeviceEncoder((8, 30, 32), BLOCK, n)
+    dec = rx.DeviceDecoder((8, 30, 32), BLOCK, nblocks)
+    d_in = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    totals = []
+    for r in range(8):
+        first = r << 30
+        rx.gen_zipf(n, 0x5EED0005, first, out=d_in)
+        for b in (0, 9999, nblocks - 1):   # the shard really is bytes [first, first + n) of the one 8 GiB stream
+            got = d_in[b * BLOCK: b * BLOCK + 4096].cpu().numpy()
+            assert (got == _host_zipf(rx, first + b * BLOCK, 4096)).all(), (r, b)
+        out, offs, status, summary = enc.encode(d_in)
+        torch.cuda.synchronize()
+        assert summary.tolist() == [0, 0], r
+        offs_h = offs.cpu().numpy()
+        total = int(offs_h[-1])
+        totals.append(total)
+        assert 0.6 < total / n < 0.72, (r, total / n)
+        for b in (0, 63, 64, 8191, nblocks - 1):
+            blk = d_in[b * BLOCK:(b + 1) * BLOCK].cpu().numpy().tobytes()
+            want, _ = ox.compress(blk, (8, 30, 32))
+            assert out[int(offs_h[b]): int(offs_h[b + 1])].cpu().numpy().tobytes() == want, (r, b)
+        d_out, d_sizes, d_status, d_sum = dec.decode(out[:total], offs)
+        torch.cuda.synchronize()
+        assert d_sum.tolist() == [0, 0] and bool((d_sizes == BLOCK).all()), r
+        assert torch.equal(d_out, d_in), r
+    assert len(set(totals)) == 8  # eight different shards, not one shard eight times
+    del enc, dec, d_in
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("r", [1, 3, 7])
+def test_config2_rank_offsets_beyond_4gib(rx, r):
+    """bench.py gives rank r the iid stream bytes [r * 4 GiB, (r+1) * 4 GiB): generator and coder at
+    those 64-bit offsets (a window of 256 blocks at the start and at the very end of the shard)."""
+    import torch
+    nb = 256
+    for first in (r * (4 << 30), (r + 1) * (4 << 30) - nb * BLOCK):
+        d_in = rx.gen_iid(nb * BLOCK, 0x5EED0001, first)
+        host = d_in.cpu().numpy()
+        assert (host[:8192] == _host_iid(first, 8192)).all() and (host[-8192:] == _host_iid(first + nb * BLOCK - 8192, 8192)).all()
+        enc = rx.DeviceEncoder((8, 30, 32), BLOCK, nb * BLOCK)
+        out, offs, status, summary = enc.encode(d_in)
+        torch.cuda.synchronize()
+        assert summary.tolist() == [0, 0]
+        offs_h = offs.cpu().numpy()
+        for b in (0, 100, nb - 1):
+            want, _ = ox.compress(host[b * BLOCK:(b + 1) * BLOCK].tobytes(), (8, 30, 32))
+            assert out[int(offs_h[b]): int(offs_h[b + 1])].cpu().numpy().tobytes() == want, (first, b)
+
+
+def test_decompress_without_max_output_grows_its_buffer(rx):
+    """redux::decompress writes to an unbounded io::Write (src/lib.rs:113).  3 MiB of one byte
+    value compresses to a few hundred bytes; the default capacity guess (64 x input, at least
+    1 MiB) is too small for it and must grow instead of failing."""
+    data = b"\0" * (3 << 20)
+    model = rx.AdaptiveTreeModel.new(rx.Parameters.new(8, 30, 32))
+    c = io.BytesIO()
+    bi, bo = rx.compress(io.BytesIO(data), c, model)
+    assert bi == len(data) and bo < 4096
+    want, _ = ox.compress(data, (8, 30, 32))
+    assert c.getvalue() == want
+    d = io.BytesIO()
+    assert rx.decompress(io.BytesIO(c.getvalue()), d, model) == (bo, len(data))
+    assert d.getvalue() == data
+    with pytest.raises(rx.OutputTooSmall):   # an explicit limit is still a limit
+        rx.decompress(io.BytesIO(c.getvalue()), io.BytesIO(), model, max_output=1 << 20)
+
+
+def test_kernel_names_follow_the_dispatch(rx):
+    import ctypes as C
+    from redux_amd import _lib
+    L = _lib.lib()
+
+    def enc(params, ptr, n, bs):
+        p = _lib.Params(*params)
+        return L.redux_encode_kernel_name(C.byref(p), C.c_void_p(ptr), n, bs).decode()
+
+    def dec(params, bs):
+        p = _lib.Params(*params)
+        return L.redux_decode_kernel_name(C.byref(p), bs).decode()
+
+    assert enc((8, 30, 32), 0, 1 << 30, 65536).startswith("k_encode_pair<false, true>")
+    assert enc((8, 14, 16), 0, 1 << 30, 65536).startswith("k_encode_pair<false, false>")
+    assert enc((8, 30, 32), 4, 1 << 30, 65536).startswith("k_encode<true, false>")     # unaligned input
+    assert enc((8, 30, 32), 0, 1 << 30, 1 << 20).startswith("k_encode<false, true>")    # u32 tree
+    assert enc((12, 14, 16), 0, 1 << 20, 65536).startswith("k_encode_any")
+    assert dec((8, 30, 32), 65536).startswith("k_decode_lock<true>")
+    assert dec((8, 22, 24), 65536).startswith("k_decode_lock<false>")
+    assert dec((8, 30, 32), 1 << 20).startswith("k_decode<false, true>")
+    assert enc((8, 3, 32), 0, 1, 1) == ""
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu(rx):
+    """`python bench.py --gpus 2` with no RANK in the environment: the parent launches two fresh rank
+    processes (here sharing cuda:0 over gloo) and passes rank 0's line through."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(GOLDEN))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--blocks", "2048", "--steps", "2",
+                        "--warmup", "1", "--rehearse-on-one-gpu", "--no-decode"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "rehearsal" in line

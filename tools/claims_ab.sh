@@ -6,6 +6,7 @@
 cd $GRAFT_REPO_ROOT
 STEPS=20 WARMUP=20 tools/run_variants.sh variants/noclaims.so variants/claims.so variants/noclaims.so variants/claims.so
 cp redux_amd/libredux_hip.so /tmp/keep2.so
+trap 'cp /tmp/keep2.so redux_amd/libredux_hip.so' EXIT  # an interrupted run must not leave a variant build as the product library
 for v in st_noclaims st_claims; do
   cp variants/$v.so redux_amd/libredux_hip.so
   echo "== $v alone"; timeout -k 10 120 python tools/enc_stamps.py

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools/kernel_ab.sh lib1.so ...  -> rocprofv3 average kernel times per build (GPU box)
 cp redux_amd/libredux_hip.so /tmp/keep.so
+trap 'cp /tmp/keep.so redux_amd/libredux_hip.so' EXIT  # an interrupted run must not leave a variant build as the product library
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for lib in "$@"; do
   cp $lib redux_amd/libredux_hip.so

@@ -2,6 +2,7 @@
 # usage: tools/wr_ab.sh lib1.so ...  -> L2 (TCC) write / eviction / fabric-write mix of the encode kernel per build (GPU box)
 # (counter names from `rocprofv3 --list-avail`: an unknown name aborts this rocprofv3 with a core dump)
 cp redux_amd/libredux_hip.so /tmp/keep.so
+trap 'cp /tmp/keep.so redux_amd/libredux_hip.so' EXIT  # an interrupted run must not leave a variant build as the product library
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 A="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode"
 for lib in "$@"; do
