@@ -1,0 +1,157 @@
+//! MI355X block coder behind `redux::compress` / `redux::decompress`.
+//!
+//! Drop this file into the reference crate as `src/hip.rs` and declare it from `src/lib.rs` with
+//! `pub mod hip;`.  It binds the C ABI of `include/redux_hip.h` (libredux_hip.so) and contains no
+//! coding logic: only argument marshalling and the mapping of status codes onto `redux::Error`
+//! (src/lib.rs:57-64).  Rust 2015 edition, like the crate (`try!`, bare trait objects).
+//!
+//! Acceleration is selected BY API: `Box<Model>` is an open trait object the GPU cannot call back
+//! into, so these functions take `&Parameters` and always code with the semantics of
+//! `AdaptiveTreeModel::new(params.clone())` (src/model/adaptive_tree.rs:36).  The existing
+//! `compress` / `decompress` / `Codec` / `Model` surface is untouched.
+//!
+//! `tests/test_rust_shim_cpu.py` in the redux_amd repository parses the `extern "C"` block below and
+//! checks every declaration against `include/redux_hip.h` (name, arity, pointer-vs-integer and
+//! integer width of each argument and of the return type).
+use std::io;
+use std::os::raw::c_int;
+use std::ptr;
+
+use super::model::Parameters;
+use super::{Error, Result};
+
+/// `redux_params` of include/redux_hip.h: the three arguments of `Parameters::new`
+/// (src/model/mod.rs:63); the library derives the other eight fields itself.
+#[repr(C)]
+pub struct ReduxParams {
+    symbol_bits: u32,
+    freq_bits: u32,
+    code_bits: u32,
+}
+
+extern "C" {
+    fn redux_params_check(symbol_bits: u32, freq_bits: u32, code_bits: u32) -> c_int;
+    fn redux_device_supports(p: *const ReduxParams) -> c_int;
+    fn redux_block_count(in_len: u64, block_size: u32) -> u64;
+    fn redux_encode_bound(p: *const ReduxParams, in_len: u64, block_size: u32) -> u64;
+    fn redux_encode_blocks(p: *const ReduxParams, input: *const u8, in_len: u64, block_size: u32,
+                           out: *mut u8, out_cap: u64, out_offsets: *mut u64,
+                           block_status: *mut i32) -> c_int;
+    fn redux_decode_blocks(p: *const ReduxParams, input: *const u8, in_offsets: *const u64,
+                           nblocks: u64, block_size: u32, out: *mut u8, out_cap: u64,
+                           out_sizes: *mut u32, block_status: *mut i32) -> c_int;
+    fn redux_compress(p: *const ReduxParams, input: *const u8, in_len: u64, out: *mut u8,
+                      out_cap: u64, bytes_in: *mut u64, bytes_out: *mut u64) -> c_int;
+    fn redux_decompress(p: *const ReduxParams, input: *const u8, in_len: u64, out: *mut u8,
+                        out_cap: u64, bytes_in: *mut u64, bytes_out: *mut u64) -> c_int;
+}
+
+/// Status codes of include/redux_hip.h -> `redux::Error` (src/lib.rs:57-64).
+fn status(st: c_int) -> Result<()> {
+    match st {
+        0 => Ok(()),
+        1 => Err(Error::Eof),
+        2 => Err(Error::InvalidInput),
+        4 => Err(Error::IoError(io::Error::new(io::ErrorKind::Other, "redux_hip: output too small"))),
+        5 => Err(Error::IoError(io::Error::new(io::ErrorKind::Other, "redux_hip: parameters unsupported on the device"))),
+        _ => Err(Error::IoError(io::Error::new(io::ErrorKind::Other, "redux_hip: HIP runtime error"))),
+    }
+}
+
+fn c_params(p: &Parameters) -> ReduxParams {
+    ReduxParams { symbol_bits: p.symbol_bits as u32, freq_bits: p.freq_bits as u32, code_bits: p.code_bits as u32 }
+}
+
+/// `true` when the device implements these parameters (`symbol_bits <= 16`); a caller may route
+/// everything else to the pure-Rust `redux::compress`.  The library itself has no CPU fallback.
+pub fn supports(p: &Parameters) -> bool {
+    let cp = c_params(p);
+    unsafe {
+        redux_params_check(cp.symbol_bits, cp.freq_bits, cp.code_bits) == 0 && redux_device_supports(&cp) == 0
+    }
+}
+
+/// One `redux::compress` per block of `block_size` bytes, all blocks coded in parallel on the GPU.
+/// Returns the dense streams and `nblocks + 1` offsets; block `b` is
+/// `out[offsets[b] as usize..offsets[b + 1] as usize]` and is byte-identical to
+/// `redux::compress(&mut &data[b * block_size..][..len_b], .., AdaptiveTreeModel::new(p.clone()))`.
+pub fn compress_blocks(data: &[u8], block_size: u32, p: &Parameters) -> Result<(Vec<u8>, Vec<u64>)> {
+    if block_size == 0 {
+        return Err(Error::InvalidInput);
+    }
+    let cp = c_params(p);
+    unsafe {
+        try!(status(redux_device_supports(&cp)));
+        let nb = redux_block_count(data.len() as u64, block_size) as usize;
+        let cap = redux_encode_bound(&cp, data.len() as u64, block_size) as usize;
+        let mut out = vec![0u8; cap];
+        let mut offs = vec![0u64; nb + 1];
+        try!(status(redux_encode_blocks(&cp, data.as_ptr(), data.len() as u64, block_size,
+                                        out.as_mut_ptr(), cap as u64, offs.as_mut_ptr(), ptr::null_mut())));
+        out.truncate(offs[nb] as usize);
+        Ok((out, offs))
+    }
+}
+
+/// Inverse of `compress_blocks`: block `b` of the result is `out[b * block_size..][..sizes[b]]`.
+pub fn decompress_blocks(streams: &[u8], offsets: &[u64], block_size: u32, p: &Parameters) -> Result<(Vec<u8>, Vec<u32>)> {
+    if block_size == 0 || offsets.is_empty() || offsets[offsets.len() - 1] as usize > streams.len() {
+        return Err(Error::InvalidInput);
+    }
+    let cp = c_params(p);
+    let nb = offsets.len() - 1;
+    unsafe {
+        try!(status(redux_device_supports(&cp)));
+        let mut out = vec![0u8; nb * block_size as usize];
+        let mut sizes = vec![0u32; nb];
+        try!(status(redux_decode_blocks(&cp, streams.as_ptr(), offsets.as_ptr(), nb as u64, block_size,
+                                        out.as_mut_ptr(), out.len() as u64, sizes.as_mut_ptr(), ptr::null_mut())));
+        Ok((out, sizes))
+    }
+}
+
+/// Same signature shape and same bytes as `redux::compress` (src/lib.rs:102-109) with an
+/// `AdaptiveTreeModel`: the whole stream is ONE block, coded by one GPU lane.  Correct, serial;
+/// `compress_blocks` is the accelerated path.
+pub fn compress(istream: &mut io::Read, ostream: &mut io::Write, p: &Parameters) -> Result<(u64, u64)> {
+    let mut data = Vec::new();
+    try!(istream.read_to_end(&mut data).map_err(Error::IoError));
+    let cp = c_params(p);
+    unsafe {
+        try!(status(redux_device_supports(&cp)));
+        let bs = if data.is_empty() { 1 } else { data.len() as u32 };
+        let cap = redux_encode_bound(&cp, data.len() as u64, bs) as usize;
+        let mut out = vec![0u8; cap];
+        let (mut bi, mut bo) = (0u64, 0u64);
+        try!(status(redux_compress(&cp, data.as_ptr(), data.len() as u64, out.as_mut_ptr(), cap as u64, &mut bi, &mut bo)));
+        try!(ostream.write_all(&out[..bo as usize]).map_err(Error::IoError));
+        Ok((bi, bo))
+    }
+}
+
+/// `redux::decompress` (src/lib.rs:113-120).  The reference writes to an unbounded `io::Write`;
+/// the C ABI wants a capacity, so the buffer grows (x8) until the stream fits or the ABI's
+/// one-block limit is reached.  Returns (compressed bytes the reader fetched, bytes written).
+pub fn decompress(istream: &mut io::Read, ostream: &mut io::Write, p: &Parameters) -> Result<(u64, u64)> {
+    const LIMIT: usize = 0xFFFF_FF00;
+    let mut data = Vec::new();
+    try!(istream.read_to_end(&mut data).map_err(Error::IoError));
+    let cp = c_params(p);
+    let mut cap = std::cmp::max(64 * data.len(), 1 << 20);
+    unsafe {
+        try!(status(redux_device_supports(&cp)));
+        loop {
+            cap = std::cmp::min(cap, LIMIT);
+            let mut out = vec![0u8; cap];
+            let (mut bi, mut bo) = (0u64, 0u64);
+            let st = redux_decompress(&cp, data.as_ptr(), data.len() as u64, out.as_mut_ptr(), cap as u64, &mut bi, &mut bo);
+            if st == 4 && cap < LIMIT {
+                cap *= 8;
+                continue;
+            }
+            try!(status(st));
+            try!(ostream.write_all(&out[..bo as usize]).map_err(Error::IoError));
+            return Ok((bi, bo));
+        }
+    }
+}
