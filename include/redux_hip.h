@@ -20,7 +20,11 @@
  *   - The caller owns every buffer.  Host-pointer calls are synchronous.  `_dev` calls take
  *     device pointers, enqueue on `stream` (a hipStream_t passed as void*, NULL = default
  *     stream), never allocate, never synchronise and keep no pointer after they return.
- *   - Re-entrant: no global mutable state.
+ *   - Thread-safe.  The `_dev` calls and the geometry helpers keep no state at all.  The
+ *     host-pointer calls share ONE lazily created, mutex-guarded context per device (chunk slots
+ *     in HBM, pinned staging, streams; grown on demand, never shrunk, freed by
+ *     redux_host_release()): calls from several host threads are safe and run one after the other.
+ *   - The `_dev` calls launch on HIP's CURRENT device; every pointer must belong to it.
  */
 #ifndef REDUX_HIP_H
 #define REDUX_HIP_H
@@ -66,6 +70,11 @@ uint64_t redux_encode_workspace_bytes(const redux_params *p, uint64_t in_len, ui
 uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, uint32_t block_size);
 
 /* ---- host-pointer, synchronous ------------------------------------------------------
+ * Inside, a call is a pipeline over chunks of whole blocks (~64 MiB): CPU threads stage the
+ * caller's bytes into pinned memory, H2D, the chunk's kernels on its own stream, D2H -- so the
+ * transfers of later chunks hide under the kernels of earlier ones (redux_amd/csrc/redux_host.hpp).
+ * No hipMalloc / hipHostMalloc happens in the steady state (same or smaller shapes than before).
+ *
  * redux_encode_blocks: replaces one redux::compress call per block (src/lib.rs:102-109).
  *   out          dense concatenation of the per-block streams
  *   out_offsets  nblocks+1 entries; block b's stream is out[out_offsets[b] .. out_offsets[b+1])
@@ -93,6 +102,16 @@ int redux_compress(const redux_params *p, const uint8_t *in, uint64_t in_len, ui
                    uint64_t *bytes_in, uint64_t *bytes_out);
 int redux_decompress(const redux_params *p, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
                      uint64_t *bytes_in, uint64_t *bytes_out);
+
+/* Frees every per-device context of the host-pointer calls (they are rebuilt on the next call).
+ * redux_host_allocations: hipMalloc + hipHostMalloc calls the contexts have made so far -- a
+ * harness checks that it does not move in the steady state. */
+int      redux_host_release(void);
+uint64_t redux_host_allocations(void);
+/* Diagnostic: the timeline of the last host-pointer call on the current device, four doubles per
+ * chunk (seconds since the call began): staging begins, device work enqueued, kernels done, results
+ * in caller memory.  Copies up to cap doubles, returns how many there are. */
+uint64_t redux_host_trace(double *out, uint64_t cap);
 
 /* ---- device-pointer, stream-ordered --------------------------------------------------
  * Same contracts with every pointer in device memory.  d_workspace must hold

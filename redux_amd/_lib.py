@@ -39,6 +39,9 @@ SIGNATURES = {
     "redux_decode_blocks": (C.c_int, [_PP, _V, _V, _U64, _U32, _V, _U64, _V, _V]),
     "redux_compress": (C.c_int, [_PP, _V, _U64, _V, _U64, C.POINTER(_U64), C.POINTER(_U64)]),
     "redux_decompress": (C.c_int, [_PP, _V, _U64, _V, _U64, C.POINTER(_U64), C.POINTER(_U64)]),
+    "redux_host_release": (C.c_int, []),
+    "redux_host_allocations": (_U64, []),
+    "redux_host_trace": (_U64, [C.POINTER(C.c_double), _U64]),
     "redux_encode_blocks_dev": (C.c_int, [_PP, _V, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
     "redux_decode_blocks_dev": (C.c_int, [_PP, _V, _V, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
     "redux_encode_slots_dev": (C.c_int, [_PP, _V, _U64, _U32, _V, _V, _U64, _V]),

@@ -250,6 +250,8 @@ static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p)
 
 } // namespace redux
 
+#include "redux_host.hpp"
+
 using namespace redux;
 
 extern "C" {
@@ -477,45 +479,7 @@ int redux_encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_le
         return st;
     if (block_size == 0 || !out || !out_offsets || (in_len && !in))
         return REDUX_INVALID_INPUT;
-    const Geometry g = geometry(p, in_len, block_size);
-    uint8_t *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr;
-    uint64_t *d_off = nullptr;
-    int32_t  *d_st = nullptr, *d_sum = nullptr;
-    int       rc = REDUX_OK;
-    int32_t   summary[2] = {0, 0};
-#define TRY_GOTO(expr)                                                                                 \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) {                                                                        \
-            fprintf(stderr, "redux_hip: %s failed: %s\n", #expr, hipGetErrorString(e_));              \
-            rc = REDUX_IO_ERROR;                                                                       \
-            goto done;                                                                                 \
-        }                                                                                              \
-    } while (0)
-    TRY_GOTO(hipMalloc((void **)&d_in, in_len ? in_len : 16));
-    TRY_GOTO(hipMalloc((void **)&d_out, out_cap ? out_cap : 16));
-    TRY_GOTO(hipMalloc((void **)&d_ws, g.total));
-    TRY_GOTO(hipMalloc((void **)&d_off, (g.nblocks + 1) * 8));
-    TRY_GOTO(hipMalloc((void **)&d_st, g.nblocks * 4));
-    TRY_GOTO(hipMalloc((void **)&d_sum, 8));
-    if (in_len)
-        TRY_GOTO(hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice));
-    TRY_GOTO(hipMemset(d_sum, 0, 8));
-    rc = redux_encode_blocks_dev(p, d_in, in_len, block_size, d_out, out_cap, d_off, d_st, d_sum, d_ws, g.total, nullptr);
-    if (rc != REDUX_OK)
-        goto done;
-    TRY_GOTO(hipDeviceSynchronize());
-    TRY_GOTO(hipMemcpy(out_offsets, d_off, (g.nblocks + 1) * 8, hipMemcpyDeviceToHost));
-    TRY_GOTO(hipMemcpy(summary, d_sum, 8, hipMemcpyDeviceToHost));
-    if (block_status)
-        TRY_GOTO(hipMemcpy(block_status, d_st, g.nblocks * 4, hipMemcpyDeviceToHost));
-    if (out_offsets[g.nblocks] <= out_cap)
-        TRY_GOTO(hipMemcpy(out, d_out, out_offsets[g.nblocks], hipMemcpyDeviceToHost));
-    rc = summary[0];
-done:
-    hipFree(d_in); hipFree(d_out); hipFree(d_ws); hipFree(d_off); hipFree(d_st); hipFree(d_sum);
-    return rc;
-#undef TRY_GOTO
+    return host::encode_blocks(p, in, in_len, block_size, out, out_cap, out_offsets, block_status); // redux_host.hpp
 }
 
 int redux_compress(const redux_params *p, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
@@ -677,54 +641,10 @@ static int decode_blocks_host(const redux_params *p, const uint8_t *in, const ui
         return REDUX_OK;
     if (out_cap < nblocks * (uint64_t)block_size)
         return REDUX_OUTPUT_TOO_SMALL;
-    const uint64_t in_len = in_offsets[nblocks];
-    const uint64_t wsb    = redux_decode_workspace_bytes(p, nblocks, block_size);
-    uint8_t  *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr;
-    uint64_t *d_off = nullptr;
-    uint32_t *d_sz = nullptr;
-    uint64_t *d_used = nullptr;
-    int32_t  *d_st = nullptr, *d_sum = nullptr;
-    int       rc = REDUX_OK;
-    int32_t   summary[2] = {0, 0};
-#define TRY_GOTO(expr)                                                                                 \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) {                                                                        \
-            fprintf(stderr, "redux_hip: %s failed: %s\n", #expr, hipGetErrorString(e_));              \
-            rc = REDUX_IO_ERROR;                                                                       \
-            goto done;                                                                                 \
-        }                                                                                              \
-    } while (0)
-    TRY_GOTO(hipMalloc((void **)&d_in, in_len + 16));
-    TRY_GOTO(hipMalloc((void **)&d_out, nblocks * (uint64_t)block_size));
-    TRY_GOTO(hipMalloc((void **)&d_ws, wsb));
-    TRY_GOTO(hipMalloc((void **)&d_off, (nblocks + 1) * 8));
-    TRY_GOTO(hipMalloc((void **)&d_sz, nblocks * 4));
-    TRY_GOTO(hipMalloc((void **)&d_st, nblocks * 4));
-    TRY_GOTO(hipMalloc((void **)&d_sum, 8));
-    if (in_used)
-        TRY_GOTO(hipMalloc((void **)&d_used, nblocks * 8));
-    if (in_len)
-        TRY_GOTO(hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice));
-    TRY_GOTO(hipMemcpy(d_off, in_offsets, (nblocks + 1) * 8, hipMemcpyHostToDevice));
-    TRY_GOTO(hipMemset(d_sum, 0, 8));
-    rc = decode_blocks_dev_impl(p, d_in, d_off, nblocks, block_size, d_out, nblocks * (uint64_t)block_size, d_sz, d_st,
-                                d_sum, d_ws, wsb, nullptr, d_used);
-    if (rc != REDUX_OK)
-        goto done;
-    TRY_GOTO(hipDeviceSynchronize());
-    TRY_GOTO(hipMemcpy(out_sizes, d_sz, nblocks * 4, hipMemcpyDeviceToHost));
-    if (in_used)
-        TRY_GOTO(hipMemcpy(in_used, d_used, nblocks * 8, hipMemcpyDeviceToHost));
-    TRY_GOTO(hipMemcpy(summary, d_sum, 8, hipMemcpyDeviceToHost));
-    if (block_status)
-        TRY_GOTO(hipMemcpy(block_status, d_st, nblocks * 4, hipMemcpyDeviceToHost));
-    TRY_GOTO(hipMemcpy(out, d_out, nblocks * (uint64_t)block_size, hipMemcpyDeviceToHost));
-    rc = summary[0];
-done:
-    hipFree(d_in); hipFree(d_out); hipFree(d_ws); hipFree(d_off); hipFree(d_sz); hipFree(d_st); hipFree(d_sum); hipFree(d_used);
-    return rc;
-#undef TRY_GOTO
+    if (in_offsets[nblocks] && !in)
+        return REDUX_INVALID_INPUT;
+    return host::decode_blocks(p, in, in_offsets, nblocks, block_size, out, out_cap, out_sizes, block_status, in_used,
+                               decode_blocks_dev_impl); // redux_host.hpp
 }
 
 int redux_decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
@@ -881,6 +801,31 @@ int redux_static_decode_blocks_dev(const redux_params *p, const uint32_t *cum, c
         k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
     HIP_TRY(hipGetLastError());
     return REDUX_OK;
+}
+
+int redux_host_release(void) { return host::ctx_release_all(); }
+
+uint64_t redux_host_allocations(void)
+{
+    uint64_t n = 0;
+    std::lock_guard<std::mutex> l(host::g_ctx_mu);
+    for (const host::Ctx &c : host::g_ctx)
+        n += c.allocs;
+    return n;
+}
+
+/* Diagnostic: timeline of the last host-pointer call on the current device (redux_host.hpp, Ctx::trace). */
+uint64_t redux_host_trace(double *out, uint64_t cap)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
+        return 0;
+    host::Ctx &c = host::g_ctx[dev];
+    std::lock_guard<std::mutex> l(c.mu);
+    const uint64_t n = c.trace.size() < cap ? c.trace.size() : cap;
+    for (uint64_t i = 0; i < n; i++)
+        out[i] = c.trace[i];
+    return c.trace.size();
 }
 
 int redux_gen_iid_dev(void *d_out, uint64_t len, uint64_t first_byte, uint64_t seed, void *stream)

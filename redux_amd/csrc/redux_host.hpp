@@ -1,0 +1,598 @@
+// redux_host.hpp -- the host-pointer side of the C ABI (redux_encode_blocks, redux_decode_blocks,
+// redux_compress, redux_decompress): what a Rust / C / ctypes caller holding plain host memory binds.
+//
+// A call is a pipeline over CHUNKS of whole blocks:
+//
+//   caller memory --(N CPU threads)--> pinned ring --(H2D DMA)--> chunk slot in HBM
+//        --> coder kernels of that chunk (its own HIP stream) --> dense chunk output
+//        --(D2H DMA)--> caller memory
+//
+// Why it looks like this (numbers: tools/ubench/pcie.hip on the MI355X box, profiles/r02_host_abi/):
+//   * hipMalloc / hipFree / hipHostMalloc cost milliseconds to hundreds of milliseconds: everything is
+//     allocated once, kept in a per-device context and only ever grown (redux_host_release() frees it).
+//     The context is guarded by one mutex: concurrent calls are safe and serialise.
+//   * H2D from pageable memory through the runtime's own staging runs at 29 GB/s, from pinned memory at
+//     57 GB/s, and 4 CPU threads fill a pinned buffer at 76 GB/s: the input is staged by a small pool of
+//     copy threads (alive for the duration of the call) through a ring of pinned pieces.
+//   * a block is a serial chain: the coder kernel of ANY number of 64 KiB blocks takes ~12 ms (decode
+//     ~28 ms).  Eight chunks are therefore in flight on eight streams -- a chunk of 128 MiB is 32
+//     workgroups, the chip holds 1024 -- so that the PCIe transfers of later chunks hide under the
+//     kernels of earlier ones and only ONE kernel latency is exposed at the end of the call.
+//   * the way back is one DMA per chunk straight into the caller's (pageable) memory, issued by a drain
+//     thread when the chunk's event fires, so that draining chunk k never delays staging and launching
+//     chunk k+8.  Nothing that depends on a running kernel is ever put into a copy queue: the SDMA
+//     queues are in order, and a 16 KiB result copy waiting for its kernel blocks every copy behind it.
+//
+// Included by redux_hip.hip (one translation unit) after the _dev entry points it drives.
+#pragma once
+
+#include "../../include/redux_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <stdint.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+
+namespace redux {
+namespace host {
+
+// The HIP runtime multiplexes the streams of a process onto FOUR hardware queues per priority level
+// (GPU_MAX_HW_QUEUES), the null stream holds one of the normal-priority ones, and streams that share a
+// queue run one after the other (tools/ubench/queues.hip: 3 default-priority streams run at once, the
+// 4th waits; 4 high- + 4 low-priority streams all run at once).  Measured with 16 default-priority
+// compute streams + a copy stream + a drain stream: 2.6 chunk kernels in flight, 13 GB/s.
+// So: eight streams, four created at the highest and four at the lowest priority (none at the
+// application's own level), chunk k does EVERYTHING (its H2D, its kernels, its D2H) on stream k % 8,
+// and chunks are large enough that eight kernels in flight outrun the PCIe link:
+//   chunk bytes / PCIe rate >= kernel latency / 8   ->  >= 78 MB (encode, 12.5 ms), >= 175 MB (decode, 28 ms).
+constexpr int      kSlots      = 8;             // chunk slots in HBM = streams (a slot is reused once its chunk has been drained)
+constexpr int      kStreams    = kSlots;
+constexpr int      kPieces     = 8;             // pinned staging ring
+constexpr uint64_t kPieceBytes = 16ull << 20;
+constexpr uint64_t kEncChunkMax = 128ull << 20; // input bytes per chunk
+constexpr uint64_t kDecChunkMax = 256ull << 20; // output bytes per chunk
+constexpr uint64_t kChunkMin    = 16ull << 20;
+constexpr int      kCopyThreads = 4;            // incl. the calling thread
+
+// ---- N threads that copy one buffer together -------------------------------------------------
+class CopyPool {
+    int                      n_;
+    std::vector<std::thread> th_;
+    std::mutex               m_;
+    std::condition_variable  go_, done_;
+    uint64_t                 gen_ = 0;
+    int                      pending_ = 0;
+    bool                     stop_ = false;
+    char                    *d_ = nullptr;
+    const char              *s_ = nullptr;
+    size_t                   len_ = 0;
+
+    void worker(int id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> l(m_);
+            go_.wait(l, [&] { return stop_ || gen_ != seen; });
+            if (stop_)
+                return;
+            seen = gen_;
+            char *d = d_; const char *s = s_; const size_t len = len_;
+            l.unlock();
+            const size_t a = len * (size_t)(id + 1) / (size_t)(n_ + 1), b = len * (size_t)(id + 2) / (size_t)(n_ + 1);
+            memcpy(d + a, s + a, b - a);
+            l.lock();
+            if (--pending_ == 0)
+                done_.notify_one();
+        }
+    }
+
+public:
+    explicit CopyPool(int helpers) : n_(helpers)
+    {
+        for (int i = 0; i < n_; i++)
+            th_.emplace_back([this, i] { worker(i); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        go_.notify_all();
+        for (auto &t : th_)
+            t.join();
+    }
+    void copy(void *dst, const void *src, size_t len)
+    {
+        if (len < (1u << 20) || n_ == 0) {
+            memcpy(dst, src, len);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(m_);
+            d_ = (char *)dst; s_ = (const char *)src; len_ = len; pending_ = n_; gen_++;
+        }
+        go_.notify_all();
+        memcpy(dst, src, len / (size_t)(n_ + 1)); // slice 0 on the calling thread
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [&] { return pending_ == 0; });
+    }
+};
+
+// ---- persistent per-device context -----------------------------------------------------------
+struct Buf {
+    void  *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Slot {          // one chunk in flight
+    Buf d_in, d_ws, d_out, d_off, d_sz, d_st, d_sum, d_used; // device
+    Buf h_off, h_sz, h_st, h_sum, h_used;                    // pinned mirrors of the small arrays
+    hipEvent_t done = nullptr;                               // recorded after the chunk's kernels and small D2H copies
+};
+
+struct Ctx {
+    std::mutex  mu;
+    int         device = -1;
+    bool        ready = false;
+    hipStream_t stream[kStreams] = {};
+    hipStream_t drain = nullptr; // bulk D2H, issued by the drain thread once a chunk's event has fired
+    Slot        slot[kSlots];
+    void       *piece[kPieces] = {};      // input staging ring
+    hipEvent_t  piece_free[kPieces] = {};
+    uint64_t    allocs = 0; // hipMalloc / hipHostMalloc calls so far (redux_host_allocations)
+    // timeline of the last call, seconds since its start: per chunk {staging begins, device work enqueued,
+    // kernels done (drain thread saw the event), results in caller memory}; trace[0..3] of chunk 0 etc.
+    std::vector<double> trace;
+    double              t0 = 0;
+};
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static Ctx g_ctx[16];
+static std::mutex g_ctx_mu;
+
+#define HOST_TRY(expr)                                                                                 \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            fprintf(stderr, "redux_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_),       \
+                    __FILE__, __LINE__);                                                               \
+            return REDUX_IO_ERROR;                                                                     \
+        }                                                                                              \
+    } while (0)
+
+static int grow_dev(Ctx &c, Buf &b, size_t need)
+{
+    if (b.cap >= need)
+        return REDUX_OK;
+    if (b.p)
+        HOST_TRY(hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    const size_t cap = (need + need / 8 + 4095) & ~(size_t)4095;
+    HOST_TRY(hipMalloc(&b.p, cap));
+    c.allocs++;
+    b.cap = cap;
+    return REDUX_OK;
+}
+
+static int grow_pinned(Ctx &c, Buf &b, size_t need)
+{
+    if (b.cap >= need)
+        return REDUX_OK;
+    if (b.p)
+        HOST_TRY(hipHostFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    const size_t cap = (need + need / 8 + 4095) & ~(size_t)4095;
+    HOST_TRY(hipHostMalloc(&b.p, cap, hipHostMallocDefault));
+    c.allocs++;
+    b.cap = cap;
+    return REDUX_OK;
+}
+
+static int ctx_get(Ctx **out)
+{
+    int dev = 0;
+    HOST_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16)
+        return REDUX_UNSUPPORTED;
+    Ctx &c = g_ctx[dev];
+    std::lock_guard<std::mutex> l(g_ctx_mu);
+    if (!c.ready) {
+        c.device = dev;
+        int pri_lo = 0, pri_hi = 0; // numerically: lo = least urgent, hi = most urgent
+        HOST_TRY(hipDeviceGetStreamPriorityRange(&pri_lo, &pri_hi));
+        for (int i = 0; i < kStreams; i++)
+            HOST_TRY(hipStreamCreateWithPriority(&c.stream[i], hipStreamNonBlocking, (i & 1) ? pri_hi : pri_lo));
+        HOST_TRY(hipStreamCreateWithFlags(&c.drain, hipStreamNonBlocking));
+        for (int i = 0; i < kSlots; i++)
+            HOST_TRY(hipEventCreateWithFlags(&c.slot[i].done, hipEventDisableTiming));
+        for (int i = 0; i < kPieces; i++) {
+            HOST_TRY(hipHostMalloc(&c.piece[i], kPieceBytes, hipHostMallocDefault));
+            HOST_TRY(hipEventCreateWithFlags(&c.piece_free[i], hipEventDisableTiming));
+            c.allocs++;
+        }
+        c.ready = true;
+    }
+    *out = &c;
+    return REDUX_OK;
+}
+
+static void free_buf_dev(Buf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+static void free_buf_pin(Buf &b) { if (b.p) (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+
+static int ctx_release_all()
+{
+    std::lock_guard<std::mutex> l(g_ctx_mu);
+    for (Ctx &c : g_ctx) {
+        if (!c.ready)
+            continue;
+        std::lock_guard<std::mutex> lc(c.mu);
+        (void)hipSetDevice(c.device);
+        (void)hipDeviceSynchronize();
+        for (Slot &s : c.slot) {
+            free_buf_dev(s.d_in); free_buf_dev(s.d_ws); free_buf_dev(s.d_out); free_buf_dev(s.d_off); free_buf_dev(s.d_sz);
+            free_buf_dev(s.d_st); free_buf_dev(s.d_sum); free_buf_dev(s.d_used);
+            free_buf_pin(s.h_off); free_buf_pin(s.h_sz); free_buf_pin(s.h_st); free_buf_pin(s.h_sum); free_buf_pin(s.h_used);
+            if (s.done) (void)hipEventDestroy(s.done);
+            s.done = nullptr;
+        }
+        for (int i = 0; i < kPieces; i++) {
+            if (c.piece[i]) (void)hipHostFree(c.piece[i]);
+            if (c.piece_free[i]) (void)hipEventDestroy(c.piece_free[i]);
+            c.piece[i] = nullptr; c.piece_free[i] = nullptr;
+        }
+        for (int i = 0; i < kStreams; i++) {
+            if (c.stream[i]) (void)hipStreamDestroy(c.stream[i]);
+            c.stream[i] = nullptr;
+        }
+        if (c.drain) (void)hipStreamDestroy(c.drain);
+        c.drain = nullptr;
+        c.ready = false;
+    }
+    return REDUX_OK;
+}
+
+// ---- hand-over between the issuing thread and the drain thread -----------------------------------
+struct Handover {
+    std::mutex              m;
+    std::condition_variable cv;
+    uint64_t                issued = 0;  // chunks whose device work has been enqueued
+    uint64_t                drained = 0; // chunks whose results are in the caller's memory
+    int                     error = REDUX_OK;
+    bool                    abort = false;
+};
+
+// stage `len` host bytes into the slot's device input at byte offset 0, through the pinned ring, on `s`
+static int stage_h2d(Ctx &c, CopyPool &pool, uint64_t &piece_no, void *d_dst, const uint8_t *src, uint64_t len, hipStream_t s)
+{
+    for (uint64_t o = 0; o < len; o += kPieceBytes) {
+        const uint64_t n = len - o < kPieceBytes ? len - o : kPieceBytes;
+        const int      k = (int)(piece_no % kPieces);
+        if (piece_no >= (uint64_t)kPieces)
+            HOST_TRY(hipEventSynchronize(c.piece_free[k])); // the H2D that last read this piece has finished
+        pool.copy(c.piece[k], src + o, n);
+        HOST_TRY(hipMemcpyAsync((uint8_t *)d_dst + o, c.piece[k], n, hipMemcpyHostToDevice, s));
+        HOST_TRY(hipEventRecord(c.piece_free[k], s));
+        piece_no++;
+    }
+    return REDUX_OK;
+}
+
+// `len` device bytes -> caller memory on the drain stream.  The destination is pageable: the runtime
+// pins it on the fly and DMAs straight into it at ~55 GB/s -- no second CPU pass over host DRAM, whose
+// bandwidth the staging threads and both DMA directions already share.  (An own pinned ring + copy
+// threads on this side measured 15 % slower on 4 GiB for that reason.)
+static int drain_d2h(Ctx &c, uint8_t *dst, const void *d_src, uint64_t len)
+{
+    HOST_TRY(hipMemcpyAsync(dst, d_src, len, hipMemcpyDeviceToHost, c.drain));
+    HOST_TRY(hipStreamSynchronize(c.drain));
+    return REDUX_OK;
+}
+
+// blocks per chunk: whole 64-block waves; an eighth of the call (eight chunks in flight), within
+// [kChunkMin, chunk_max] bytes of payload
+static uint64_t chunk_blocks_for(uint64_t nblocks, uint32_t block_size, uint64_t chunk_max)
+{
+    uint64_t bytes = (nblocks * (uint64_t)block_size + kSlots - 1) / kSlots;
+    bytes = bytes < kChunkMin ? kChunkMin : bytes > chunk_max ? chunk_max : bytes;
+    uint64_t cb = (bytes + block_size - 1) / block_size;
+    cb = (cb + 63) / 64 * 64;
+    return cb < nblocks ? cb : nblocks;
+}
+
+// ================================================================================================
+// encode
+// ================================================================================================
+static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_len, uint32_t block_size, uint8_t *out,
+                         uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
+{
+    Ctx *cp = nullptr;
+    int  rc = ctx_get(&cp);
+    if (rc != REDUX_OK)
+        return rc;
+    Ctx &c = *cp;
+    std::lock_guard<std::mutex> lock(c.mu);
+
+    const uint64_t nblocks = redux_block_count(in_len, block_size);
+    const uint64_t cb      = chunk_blocks_for(nblocks, block_size, kEncChunkMax);
+    const uint64_t nchunks = (nblocks + cb - 1) / cb;
+    const uint64_t chunk_in = cb * (uint64_t)block_size; // bytes of a full chunk
+    const uint64_t ws_bytes = redux_encode_workspace_bytes(p, chunk_in < in_len ? chunk_in : in_len, block_size);
+    const uint64_t bound    = redux_encode_bound(p, chunk_in < in_len ? chunk_in : in_len, block_size);
+    const int      nslots   = (int)(nchunks < (uint64_t)kSlots ? nchunks : (uint64_t)kSlots);
+    for (int i = 0; i < nslots; i++) {
+        Slot &s = c.slot[i];
+        if ((rc = grow_dev(c, s.d_in, (chunk_in < in_len ? chunk_in : in_len) + 16)) || (rc = grow_dev(c, s.d_ws, ws_bytes + 256)) ||
+            (rc = grow_dev(c, s.d_out, bound + 16)) || (rc = grow_dev(c, s.d_off, (cb + 1) * 8)) || (rc = grow_dev(c, s.d_st, cb * 4)) ||
+            (rc = grow_dev(c, s.d_sum, 8)) || (rc = grow_pinned(c, s.h_off, (cb + 1) * 8)) || (rc = grow_pinned(c, s.h_st, cb * 4)) ||
+            (rc = grow_pinned(c, s.h_sum, 8)))
+            return rc;
+    }
+
+    c.trace.assign(nchunks * 4, 0.0);
+    c.t0 = now_s();
+    Handover H;
+    int      first_bad = REDUX_OK; // first non-OK per-block status, in block order (what the _dev summary reports)
+    // ---- drain thread: results of chunk k -> caller memory, in chunk order --------------------
+    std::thread drain([&] {
+        (void)hipSetDevice(c.device);
+        uint64_t base = 0;
+        for (uint64_t k = 0; k < nchunks; k++) {
+            {
+                std::unique_lock<std::mutex> l(H.m);
+                H.cv.wait(l, [&] { return H.issued > k || H.abort; });
+                if (H.abort)
+                    return;
+            }
+            Slot          &s  = c.slot[k % kSlots];
+            const uint64_t b0 = k * cb, nb = (b0 + cb <= nblocks ? cb : nblocks - b0);
+            int            err = REDUX_OK;
+            hipStream_t st = c.stream[k % kStreams]; // idle once the chunk's event has fired
+            if (hipEventSynchronize(s.done) != hipSuccess ||
+                hipMemcpyAsync(s.h_off.p, s.d_off.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(s.h_sum.p, s.d_sum.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                err = REDUX_IO_ERROR;
+            c.trace[k * 4 + 2] = now_s() - c.t0;
+            const uint64_t *ho    = (const uint64_t *)s.h_off.p;
+            const uint64_t  total = err ? 0 : ho[nb];
+            const int32_t  *sum   = (const int32_t *)s.h_sum.p;
+            if (!err && first_bad == REDUX_OK && sum[0] != REDUX_OK)
+                first_bad = sum[0];
+            if (!err && base + total > out_cap)
+                err = REDUX_OUTPUT_TOO_SMALL;
+            if (!err && total)
+                err = drain_d2h(c, out + base, s.d_out.p, total);
+            if (!err) {
+                for (uint64_t i = 0; i <= nb; i++)
+                    out_offsets[b0 + i] = base + ho[i];
+                if (block_status)
+                    memcpy(block_status + b0, s.h_st.p, nb * 4);
+                base += total;
+            }
+            c.trace[k * 4 + 3] = now_s() - c.t0;
+            std::lock_guard<std::mutex> l(H.m);
+            if (err && H.error == REDUX_OK)
+                H.error = err;
+            H.drained = k + 1;
+            H.cv.notify_all();
+            if (err) {
+                H.abort = true;
+                return;
+            }
+        }
+    });
+
+    // ---- issuing side (this thread): stage, H2D, kernels, small D2H -----------------------------
+    {
+        CopyPool pool(kCopyThreads - 1);
+        uint64_t piece_no = 0;
+        for (uint64_t k = 0; k < nchunks && rc == REDUX_OK; k++) {
+            {
+                std::unique_lock<std::mutex> l(H.m); // the slot's previous chunk must be in the caller's memory
+                H.cv.wait(l, [&] { return H.abort || k < (uint64_t)kSlots || H.drained + kSlots > k; });
+                if (H.abort)
+                    break;
+            }
+            c.trace[k * 4 + 0] = now_s() - c.t0;
+            Slot          &s  = c.slot[k % kSlots];
+            hipStream_t    st = c.stream[k % kStreams];
+            const uint64_t b0 = k * cb, nb = (b0 + cb <= nblocks ? cb : nblocks - b0);
+            const uint64_t o0 = b0 * (uint64_t)block_size;
+            const uint64_t len = (o0 + nb * (uint64_t)block_size <= in_len) ? nb * (uint64_t)block_size : in_len - o0;
+            auto issue = [&]() -> int {
+                int r = stage_h2d(c, pool, piece_no, s.d_in.p, in + o0, len, st);
+                if (r != REDUX_OK)
+                    return r;
+                HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
+                uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
+                r = redux_encode_blocks_dev(p, s.d_in.p, len, block_size, s.d_out.p, bound, s.d_off.p, s.d_st.p, s.d_sum.p, ws,
+                                            ws_bytes, st);
+                if (r != REDUX_OK)
+                    return r;
+                // (the small result arrays are fetched by the drain thread once the event has fired: a D2H
+                // enqueued here would sit in the in-order SDMA queue until this chunk's kernels end, with
+                // every other chunk's drain copies stuck behind it -- measured: 15-20 ms stalls)
+                HOST_TRY(hipEventRecord(s.done, st));
+                return REDUX_OK;
+            };
+            rc = issue();
+            c.trace[k * 4 + 1] = now_s() - c.t0;
+            std::lock_guard<std::mutex> l(H.m);
+            if (rc != REDUX_OK) {
+                H.abort = true;
+                if (H.error == REDUX_OK)
+                    H.error = rc;
+            } else
+                H.issued = k + 1;
+            H.cv.notify_all();
+        }
+    }
+    drain.join();
+    for (int i = 0; i < kStreams; i++) // nothing of this call stays in flight
+        (void)hipStreamSynchronize(c.stream[i]);
+    if (H.error != REDUX_OK)
+        return H.error;
+    return first_bad;
+}
+
+// ================================================================================================
+// decode
+// ================================================================================================
+static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
+                         uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes, int32_t *block_status,
+                         uint64_t *in_used, int (*dev_call)(const redux_params *, const void *, const void *, uint64_t, uint32_t,
+                                                            void *, uint64_t, void *, void *, void *, void *, uint64_t, void *,
+                                                            void *))
+{
+    Ctx *cp = nullptr;
+    int  rc = ctx_get(&cp);
+    if (rc != REDUX_OK)
+        return rc;
+    Ctx &c = *cp;
+    std::lock_guard<std::mutex> lock(c.mu);
+
+    const uint64_t cb      = chunk_blocks_for(nblocks, block_size, kDecChunkMax);
+    const uint64_t nchunks = (nblocks + cb - 1) / cb;
+    const uint64_t wsb     = redux_decode_workspace_bytes(p, cb, block_size);
+    uint64_t       max_in  = 0;
+    for (uint64_t k = 0; k < nchunks; k++) {
+        const uint64_t b0 = k * cb, b1 = (b0 + cb <= nblocks ? b0 + cb : nblocks);
+        if (in_offsets[b1] < in_offsets[b0])
+            return REDUX_INVALID_INPUT;
+        const uint64_t n = in_offsets[b1] - in_offsets[b0];
+        max_in = n > max_in ? n : max_in;
+    }
+    const int nslots = (int)(nchunks < (uint64_t)kSlots ? nchunks : (uint64_t)kSlots);
+    for (int i = 0; i < nslots; i++) {
+        Slot &s = c.slot[i];
+        if ((rc = grow_dev(c, s.d_in, max_in + 32)) || (rc = grow_dev(c, s.d_ws, wsb + 256)) ||
+            (rc = grow_dev(c, s.d_out, cb * (uint64_t)block_size + 16)) || (rc = grow_dev(c, s.d_off, (cb + 1) * 8)) ||
+            (rc = grow_dev(c, s.d_sz, cb * 4)) || (rc = grow_dev(c, s.d_st, cb * 4)) || (rc = grow_dev(c, s.d_sum, 8)) ||
+            (rc = grow_dev(c, s.d_used, in_used ? cb * 8 : 8)) || (rc = grow_pinned(c, s.h_off, (cb + 1) * 8)) ||
+            (rc = grow_pinned(c, s.h_sz, cb * 4)) || (rc = grow_pinned(c, s.h_st, cb * 4)) || (rc = grow_pinned(c, s.h_sum, 8)) ||
+            (rc = grow_pinned(c, s.h_used, in_used ? cb * 8 : 8)))
+            return rc;
+    }
+
+    c.trace.assign(nchunks * 4, 0.0);
+    c.t0 = now_s();
+    Handover H;
+    int      first_bad = REDUX_OK;
+    std::thread drain([&] {
+        (void)hipSetDevice(c.device);
+        for (uint64_t k = 0; k < nchunks; k++) {
+            {
+                std::unique_lock<std::mutex> l(H.m);
+                H.cv.wait(l, [&] { return H.issued > k || H.abort; });
+                if (H.abort)
+                    return;
+            }
+            Slot          &s  = c.slot[k % kSlots];
+            const uint64_t b0 = k * cb, nb = (b0 + cb <= nblocks ? cb : nblocks - b0);
+            int            err = REDUX_OK;
+            hipStream_t st = c.stream[k % kStreams];
+            if (hipEventSynchronize(s.done) != hipSuccess ||
+                hipMemcpyAsync(s.h_sz.p, s.d_sz.p, nb * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(s.h_sum.p, s.d_sum.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                (in_used && hipMemcpyAsync(s.h_used.p, s.d_used.p, nb * 8, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+                hipStreamSynchronize(st) != hipSuccess)
+                err = REDUX_IO_ERROR;
+            c.trace[k * 4 + 2] = now_s() - c.t0;
+            if (!err) {
+                const int32_t *sum = (const int32_t *)s.h_sum.p;
+                if (first_bad == REDUX_OK && sum[0] != REDUX_OK)
+                    first_bad = sum[0];
+                err = drain_d2h(c, out + b0 * (uint64_t)block_size, s.d_out.p, nb * (uint64_t)block_size);
+            }
+            if (!err) {
+                memcpy(out_sizes + b0, s.h_sz.p, nb * 4);
+                if (block_status)
+                    memcpy(block_status + b0, s.h_st.p, nb * 4);
+                if (in_used)
+                    memcpy(in_used + b0, s.h_used.p, nb * 8);
+            }
+            c.trace[k * 4 + 3] = now_s() - c.t0;
+            std::lock_guard<std::mutex> l(H.m);
+            if (err && H.error == REDUX_OK)
+                H.error = err;
+            H.drained = k + 1;
+            H.cv.notify_all();
+            if (err) {
+                H.abort = true;
+                return;
+            }
+        }
+    });
+
+    {
+        CopyPool pool(kCopyThreads - 1);
+        uint64_t piece_no = 0;
+        for (uint64_t k = 0; k < nchunks && rc == REDUX_OK; k++) {
+            {
+                std::unique_lock<std::mutex> l(H.m);
+                H.cv.wait(l, [&] { return H.abort || k < (uint64_t)kSlots || H.drained + kSlots > k; });
+                if (H.abort)
+                    break;
+            }
+            c.trace[k * 4 + 0] = now_s() - c.t0;
+            Slot          &s  = c.slot[k % kSlots];
+            hipStream_t    st = c.stream[k % kStreams];
+            const uint64_t b0 = k * cb, nb = (b0 + cb <= nblocks ? cb : nblocks - b0);
+            const uint64_t i0 = in_offsets[b0], len = in_offsets[b0 + nb] - i0;
+            auto issue = [&]() -> int {
+                // the chunk's offsets, rebased to the chunk's first byte (the pinned mirror of the previous
+                // chunk in this slot has been consumed: that chunk is drained)
+                uint64_t *ho = (uint64_t *)s.h_off.p;
+                for (uint64_t i = 0; i <= nb; i++) {
+                    if (in_offsets[b0 + i] < i0 || (i && in_offsets[b0 + i] < in_offsets[b0 + i - 1]))
+                        return REDUX_INVALID_INPUT;
+                    ho[i] = in_offsets[b0 + i] - i0;
+                }
+                HOST_TRY(hipMemcpyAsync(s.d_off.p, ho, (nb + 1) * 8, hipMemcpyHostToDevice, st));
+                int r = stage_h2d(c, pool, piece_no, s.d_in.p, in + i0, len, st);
+                if (r != REDUX_OK)
+                    return r;
+                HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
+                uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
+                r = dev_call(p, s.d_in.p, s.d_off.p, nb, block_size, s.d_out.p, nb * (uint64_t)block_size, s.d_sz.p, s.d_st.p,
+                             s.d_sum.p, ws, wsb, st, in_used ? s.d_used.p : nullptr);
+                if (r != REDUX_OK)
+                    return r;
+                HOST_TRY(hipEventRecord(s.done, st)); // (small result arrays: fetched by the drain thread, see encode_blocks)
+                return REDUX_OK;
+            };
+            rc = issue();
+            c.trace[k * 4 + 1] = now_s() - c.t0;
+            std::lock_guard<std::mutex> l(H.m);
+            if (rc != REDUX_OK) {
+                H.abort = true;
+                if (H.error == REDUX_OK)
+                    H.error = rc;
+            } else
+                H.issued = k + 1;
+            H.cv.notify_all();
+        }
+    }
+    drain.join();
+    for (int i = 0; i < kStreams; i++)
+        (void)hipStreamSynchronize(c.stream[i]);
+    (void)out_cap;
+    if (H.error != REDUX_OK)
+        return H.error;
+    return first_bad;
+}
+
+} // namespace host
+} // namespace redux

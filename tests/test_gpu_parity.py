@@ -913,3 +913,54 @@ def test_bench_self_launch_two_ranks_on_one_gpu(rx):
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and "rehearsal" in line
+
+
+def test_host_abi_pipeline_many_chunks(rx):
+    """The host-pointer calls cut the work into chunks of whole blocks that run on several streams
+    (redux_amd/csrc/redux_host.hpp).  Inputs that span several chunks, with a ragged tail, at three
+    block sizes: every stream equals the oracle's, offsets are dense, the decode returns the bytes,
+    and a repeated call allocates nothing."""
+    import ctypes as C
+    from redux_amd import _lib
+    rng = np.random.default_rng(7)
+    text = open(os.path.join(GOLDEN, "corpora", "large", "bible.txt"), "rb").read()
+    big = np.concatenate([np.frombuffer(text, dtype=np.uint8)] * 40 + [rng.integers(0, 256, 9_000_001, dtype=np.uint8)])
+    for bs, n in ((65536, len(big)), (4096, 70_000_123), (1 << 20, len(big))):   # ~171 MB -> 3 chunks; 4 KiB blocks -> 2 chunks
+        data = big[:n]
+        out, offs, st = rx.compress_blocks(data, bs, (8, 30, 32))
+        nb = len(offs) - 1
+        assert nb == (n + bs - 1) // bs and int(offs[0]) == 0 and not st.any()
+        sample = sorted(set([0, 1, nb // 3, nb // 2, nb - 2, nb - 1] + list(rng.integers(0, nb, 12))))
+        for b in sample:
+            want, _ = ox.compress(data[b * bs:(b + 1) * bs].tobytes(), (8, 30, 32))
+            assert out[int(offs[b]): int(offs[b + 1])].tobytes() == want, (bs, b)
+        dec, sizes, dst = rx.decompress_blocks(out, offs, bs, (8, 30, 32))
+        assert not dst.any() and int(sizes.sum()) == n
+        if n % bs == 0:
+            assert (dec == data).all()
+        else:
+            assert (dec[: (nb - 1) * bs] == data[: (nb - 1) * bs]).all() and (dec[(nb - 1) * bs:][: n - (nb - 1) * bs] == data[(nb - 1) * bs:]).all()
+    a0 = _lib.lib().redux_host_allocations()
+    out2, offs2, _ = rx.compress_blocks(big, 1 << 20, (8, 30, 32))
+    assert _lib.lib().redux_host_allocations() == a0 and (offs2 == offs).all() and (out2 == out).all()
+
+
+def test_host_abi_from_two_threads_and_release(rx):
+    import threading
+    from redux_amd import _lib
+    text = open(os.path.join(GOLDEN, "corpora", "calgary", "book1"), "rb").read()
+    want, _ = ox.compress_blocks(text, BLOCK, (8, 30, 32))
+    res = {}
+
+    def work(i):
+        out, offs, st = rx.compress_blocks(text, BLOCK, (8, 30, 32))
+        dec, sizes, _ = rx.decompress_blocks(out, offs, BLOCK, (8, 30, 32))
+        res[i] = (split(out, offs) == want, b"".join(dec[b * BLOCK: b * BLOCK + int(sizes[b])].tobytes() for b in range(len(sizes))) == text)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert res == {i: (True, True) for i in range(4)}
+    assert _lib.lib().redux_host_release() == 0       # the context is rebuilt on the next call
+    out, offs, st = rx.compress_blocks(text, BLOCK, (8, 30, 32))
+    assert split(out, offs) == want
