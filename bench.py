@@ -176,7 +176,7 @@ def main():
     cp = _lib.Params(*PARAMS)
     # the kernel the library's dispatch picked for exactly these arguments (not an assumption)
     kname = _lib.lib().redux_encode_kernel_name(C.byref(cp), C.c_void_p(d_in.data_ptr()), n, BLOCK).decode()
-    dname = _lib.lib().redux_decode_kernel_name(C.byref(cp), BLOCK).decode()
+    dname = _lib.lib().redux_decode_kernel_name(C.byref(cp), None, BLOCK).decode()
     # `traffic` is not measured by this run: it is the PMC figure of a separate rocprofv3 --pmc pass
     # of this same command (tools/prof_traffic.sh), kept per workload in profiles/traffic.json
     traffic, traffic_src = None, None

@@ -172,11 +172,11 @@ int redux_static_decode_blocks_dev(const redux_params *p, const uint32_t *cum, c
 const char *redux_version(void);
 
 /* Which kernel redux_encode_slots_dev / redux_decode_blocks_dev launch for these arguments (the
- * same decision function the launch code uses; d_in only contributes its alignment).  A static
+ * same decision function the launch code uses; d_in / d_out only contribute their alignment).  A static
  * string; "" for invalid arguments.  A harness reports it next to its timings (bench.py's
  * roofline.kernel) instead of assuming the fast path was taken. */
 const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size);
-const char *redux_decode_kernel_name(const redux_params *p, uint32_t block_size);
+const char *redux_decode_kernel_name(const redux_params *p, const void *d_out, uint32_t block_size);
 
 /* Diagnostic, used by the parity tests only: *max_err = max over the integers x in [lo, hi] of
  * |v_rcp_f64(x) * x - 1| evaluated on the device.  The decoder's code-value division

@@ -25,7 +25,7 @@ _U32 = C.c_uint32
 SIGNATURES = {
     "redux_version": (C.c_char_p, []),
     "redux_encode_kernel_name": (C.c_char_p, [_PP, _V, _U64, _U32]),
-    "redux_decode_kernel_name": (C.c_char_p, [_PP, _U32]),
+    "redux_decode_kernel_name": (C.c_char_p, [_PP, _V, _U32]),
     "redux_debug_rcp_check": (C.c_int, [_U64, _U64, C.POINTER(C.c_double)]),
     "redux_debug_role_book": (C.c_int, [_PP, _U64, _U32, C.POINTER(_U64), C.POINTER(_U64)]),
     "redux_params_check": (C.c_int, [_U32, _U32, _U32]),

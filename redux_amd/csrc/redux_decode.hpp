@@ -32,6 +32,7 @@ struct DecArgs {
     uint32_t        code_bits;
     uint32_t        aligned4;   // 1: out and block_size are 4-byte multiples; 2: 16-byte multiples
     uint64_t       *in_used;    // optional: bytes of each stream the reader fetched (ByteCount, bitio/mod.rs:71)
+    uint32_t       *claims;     // k_decode_pair's per-CU role book (kClaimWords words, zero at launch)
 };
 
 // BitReader (bitio/mod.rs:78-120) as a 64-bit look-ahead register: the `cnt` not yet
@@ -306,8 +307,14 @@ __device__ __forceinline__ DecTop dec_top_new() { return {128u, 64u, 64u, 32u, 3
 // get_symbol (adaptive_tree.rs:115-136) + the high end of get_frequency (:105-113), layout above.
 // Safe for any v (lanes that are already done run it on garbage): every address stays inside
 // the 32 KiB tree.
+// before_lds(bits): called after the three register levels, before the first LDS read (k_decode_pair waits there
+// for its helper wave's update of the previous step)
+struct DecNoHook {
+    __device__ __forceinline__ void operator()(uint32_t &) const {}
+};
+template <class Hook = DecNoHook>
 __device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, const DecTop &T, uint32_t v,
-                                               uint32_t c DEC_STAMP_ARGS)
+                                               uint32_t c DEC_STAMP_ARGS, Hook before_lds = Hook())
 {
     auto ld = [&](uint32_t byte) { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + byte); };
     uint32_t q = ~v, hq = q + (c - 1u), bits = 0, q2;
@@ -326,6 +333,7 @@ __device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, 
     const uint32_t x5 = left ? c5l : c5r;
     REDUX_DEC_LEVEL(x5)
     DEC_STAMP(2, bits)
+    before_lds(bits);
     // round B: levels 4, 3 under the prefix i = bits << 5: nodes i+16; i+8, i+24 (three dwords)
     uint32_t       ib  = ((bits & 7u) << 12) | L;
     const uint32_t w16 = ld(ib + (16u << 7));
@@ -355,7 +363,7 @@ __device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, 
 // update(s+1) (adaptive_tree.rs:83-92): +1 on the levels where bit b of s is clear.  Levels 7-5
 // live in registers: node e of level b is incremented iff s lies in [e - 2^b, e), an unsigned
 // range compare + add-with-carry; levels 4-0 are fire-and-forget ds_add_u32.
-__device__ __forceinline__ void dec_update(uint32_t *lds, const uint32_t (&A)[8], DecTop &T, uint32_t s)
+__device__ __forceinline__ void dec_update_regs(DecTop &T, uint32_t s)
 {
     T.n128 += s < 128u ? 1u : 0u;
     T.n64 += s < 64u ? 1u : 0u;
@@ -364,6 +372,9 @@ __device__ __forceinline__ void dec_update(uint32_t *lds, const uint32_t (&A)[8]
     T.n96 += (s - 64u) < 32u ? 1u : 0u;
     T.n160 += (s - 128u) < 32u ? 1u : 0u;
     T.n224 += (s - 192u) < 32u ? 1u : 0u;
+}
+__device__ __forceinline__ void dec_update_lds(uint32_t *lds, const uint32_t (&A)[8], uint32_t s)
+{
     const uint32_t ss = s << 7, ns = ~s;
 #pragma unroll
     for (int b = 0; b < 5; b++) {
@@ -373,6 +384,11 @@ __device__ __forceinline__ void dec_update(uint32_t *lds, const uint32_t (&A)[8]
         __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + addr), inc, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+}
+__device__ __forceinline__ void dec_update(uint32_t *lds, const uint32_t (&A)[8], DecTop &T, uint32_t s)
+{
+    dec_update_regs(T, s);
+    dec_update_lds(lds, A, s);
 }
 
 // value = floor(((V - low + 1) * count - 1) / range) (codec.rs:129-131) in f64.  Numerator nd
@@ -425,7 +441,8 @@ struct DecLane {
 // Per-lane, predicated end of a step: decompress_symbol after the model answered
 // (codec.rs:133-161) + decompress_stream's emission (:170-172).  `may_update`: the model is not
 // frozen; `room`: p < block capacity.
-template <bool CB32>
+// LDS_UPDATE false: the LDS levels of this step's update have been applied already (k_decode_pair's helper wave)
+template <bool CB32, bool LDS_UPDATE = true>
 __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const DecFound &f, uint32_t *lds, const uint32_t (&A)[8],
                                                    uint32_t R1, double R1d, double rc, uint32_t c, uint32_t sh,
                                                    uint32_t stream_bits, uint32_t p, bool may_update, bool room,
@@ -439,8 +456,11 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
         S.n_out = p;
         return;
     }
-    if (may_update)
-        dec_update(lds, A, T, f.s);
+    if (may_update) {
+        dec_update_regs(T, f.s);
+        if (LDS_UPDATE)
+            dec_update_lds(lds, A, f.s);
+    }
     const double   Y      = __builtin_fma(R1d, rc, rc);
     const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
     const uint32_t nihigh = 0u - (S.low + (scale_div<false>(R1, Y, f.hi, c) << sh));
@@ -688,6 +708,17 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
             for (int K = 0; K < 4; K++) {
                 const double   rc = rcg[K];
                 const uint32_t c  = 257u + p + K;
+#if REDUX_DEC_DUP == 6 // what the bit reader costs: the same instructions once more on copies
+                {
+                    uint64_t bb = S.bbits; uint32_t bc = S.bcnt, rp2 = rpo, fe = fetched;
+                    asm volatile("" : "+v"(bb), "+v"(bc), "+v"(rp2), "+v"(fe));
+                    const bool     need = bc <= 32;
+                    const uint64_t add  = (uint64_t)(need ? __builtin_bswap32(fe) : 0u) << ((32 - bc) & 63);
+                    bb |= add; bc += need ? 32u : 0u; rp2 += need ? 1u : 0u;
+                    fe = ring_read(rp2);
+                    asm volatile("" ::"v"(bb), "v"(bc), "v"(rp2), "v"(fe));
+                }
+#endif
                 REDUX_DEC_READER
                 DEC_STAMP(0, S.bcnt)
                 const uint32_t R1  = (~(S.ihigh + S.low)) >> sh;
@@ -749,6 +780,32 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
                 const uint32_t e     = CB32 ? (f.eofq | k | (S.sbits - cons2)) : (f.eofq | (cb - 1u - k) | (S.sbits - cons2));
                 DEC_STAMP(5, e)
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)e < 0) == 0, 1)) {
+#if REDUX_DEC_DUP == 4 // what the LDS-level update costs: its address arithmetic and five more atomics (of zero)
+                    {
+                        const uint32_t ss = f.s << 7;
+                        uint32_t       dup_zero = 0;
+                        asm volatile("" : "+v"(dup_zero));
+#pragma unroll
+                        for (int b = 0; b < 5; b++) {
+                            const uint32_t keep = b ? (((0xFFu << b) & 0xFFu) << 7) : (0xFEu << 7);
+                            uint32_t       addr = (ss & keep) | A[b];
+                            uint32_t       inc  = ((~f.s) >> b) & dup_zero; // an opaque zero: a literal 0 turns the atomic into a fence
+                            asm volatile("" : "+v"(addr), "+v"(inc));
+                            __hip_atomic_fetch_add(lds + (addr >> 2), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+#endif
+#if REDUX_DEC_DUP == 5 // what the register levels' update costs (7 compare + add-with-carry pairs, results discarded)
+                    {
+                        DecTop T2 = T;
+                        uint32_t s2 = f.s;
+                        asm volatile("" : "+v"(s2));
+                        T2.n128 += s2 < 128u ? 1u : 0u; T2.n64 += s2 < 64u ? 1u : 0u; T2.n192 += (s2 - 128u) < 64u ? 1u : 0u;
+                        T2.n32 += s2 < 32u ? 1u : 0u; T2.n96 += (s2 - 64u) < 32u ? 1u : 0u; T2.n160 += (s2 - 128u) < 32u ? 1u : 0u;
+                        T2.n224 += (s2 - 192u) < 32u ? 1u : 0u;
+                        asm volatile("" ::"v"(T2.n128), "v"(T2.n64), "v"(T2.n192), "v"(T2.n32), "v"(T2.n96), "v"(T2.n160), "v"(T2.n224));
+                    }
+#endif
                     dec_update(lds, A, T, f.s);
                     S.low      = (low2 << j) & 0x7FFFFFFFu;
                     S.ihigh    = (ih2 << j) & 0x7FFFFFFFu;
