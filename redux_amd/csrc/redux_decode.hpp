@@ -32,7 +32,6 @@ struct DecArgs {
     uint32_t        code_bits;
     uint32_t        aligned4;   // 1: out and block_size are 4-byte multiples; 2: 16-byte multiples
     uint64_t       *in_used;    // optional: bytes of each stream the reader fetched (ByteCount, bitio/mod.rs:71)
-    uint32_t       *claims;     // k_decode_pair's per-CU role book (kClaimWords words, zero at launch)
 };
 
 // BitReader (bitio/mod.rs:78-120) as a 64-bit look-ahead register: the `cnt` not yet
@@ -307,14 +306,8 @@ __device__ __forceinline__ DecTop dec_top_new() { return {128u, 64u, 64u, 32u, 3
 // get_symbol (adaptive_tree.rs:115-136) + the high end of get_frequency (:105-113), layout above.
 // Safe for any v (lanes that are already done run it on garbage): every address stays inside
 // the 32 KiB tree.
-// before_lds(bits): called after the three register levels, before the first LDS read (k_decode_pair waits there
-// for its helper wave's update of the previous step)
-struct DecNoHook {
-    __device__ __forceinline__ void operator()(uint32_t &) const {}
-};
-template <class Hook = DecNoHook>
 __device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, const DecTop &T, uint32_t v,
-                                               uint32_t c DEC_STAMP_ARGS, Hook before_lds = Hook())
+                                               uint32_t c DEC_STAMP_ARGS)
 {
     auto ld = [&](uint32_t byte) { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + byte); };
     uint32_t q = ~v, hq = q + (c - 1u), bits = 0, q2;
@@ -333,7 +326,6 @@ __device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, 
     const uint32_t x5 = left ? c5l : c5r;
     REDUX_DEC_LEVEL(x5)
     DEC_STAMP(2, bits)
-    before_lds(bits);
     // round B: levels 4, 3 under the prefix i = bits << 5: nodes i+16; i+8, i+24 (three dwords)
     uint32_t       ib  = ((bits & 7u) << 12) | L;
     const uint32_t w16 = ld(ib + (16u << 7));
@@ -441,8 +433,7 @@ struct DecLane {
 // Per-lane, predicated end of a step: decompress_symbol after the model answered
 // (codec.rs:133-161) + decompress_stream's emission (:170-172).  `may_update`: the model is not
 // frozen; `room`: p < block capacity.
-// LDS_UPDATE false: the LDS levels of this step's update have been applied already (k_decode_pair's helper wave)
-template <bool CB32, bool LDS_UPDATE = true>
+template <bool CB32>
 __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const DecFound &f, uint32_t *lds, const uint32_t (&A)[8],
                                                    uint32_t R1, double R1d, double rc, uint32_t c, uint32_t sh,
                                                    uint32_t stream_bits, uint32_t p, bool may_update, bool room,
@@ -456,11 +447,8 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
         S.n_out = p;
         return;
     }
-    if (may_update) {
-        dec_update_regs(T, f.s);
-        if (LDS_UPDATE)
-            dec_update_lds(lds, A, f.s);
-    }
+    if (may_update)
+        dec_update(lds, A, T, f.s);
     const double   Y      = __builtin_fma(R1d, rc, rc);
     const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
     const uint32_t nihigh = 0u - (S.low + (scale_div<false>(R1, Y, f.hi, c) << sh));

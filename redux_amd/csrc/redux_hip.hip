@@ -3,8 +3,7 @@
 // One translation unit; the kernels (all hand-written for CDNA4, wave64) live in
 //   redux_coder.hpp    device building blocks: LDS tree, interval narrowing, bit output
 //   redux_encode.hpp   k_fill_rc, k_encode, k_encode_pair (default encoder)
-//   redux_decode.hpp   k_decode, k_decode_lock (one wave per 64 blocks)
-//   redux_decode_pair.hpp  k_decode_pair (default decoder: core wave + aux wave per 64 blocks)
+//   redux_decode.hpp   k_decode, k_decode_lock (default decoder)
 //   redux_pack.hpp     k_scan_sizes, k_compact: slots -> dense stream + offsets
 //   redux_any.hpp      general Parameters (symbol_bits <= 16, code_bits <= 63), one lane per block
 //   redux_synth.hpp    k_gen_iid / k_gen_zipf
@@ -17,7 +16,6 @@
 #include "redux_any.hpp"
 #include "redux_encode.hpp"
 #include "redux_decode.hpp"
-#include "redux_decode_pair.hpp"
 #include "redux_pack.hpp"
 #include "redux_synth.hpp"
 #include "redux_static.hpp"
@@ -207,7 +205,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
 // ---- which kernel a call runs: ONE decision, used by the launch code and reported by
 // redux_encode_kernel_name / redux_decode_kernel_name (bench.py's roofline.kernel) ------------
 enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Any };
-enum class DecKernel { PairCb32, Pair, LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Any };
+enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Any };
 
 // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset; otherwise
 // (giant blocks, whole-stream mode) one block per wave.
@@ -234,21 +232,15 @@ static EncKernel pick_encode_kernel(const Geometry &g, const redux_params *p, bo
     return EncKernel::SingleU32;
 }
 
-static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p, bool aligned4)
+static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p)
 {
     if (g.any)
         return DecKernel::Any;
     bool lock = g.u16 && !g.fixup;
-    bool pair = lock && aligned4; // the pair's aux wave stores whole dwords
-#ifdef REDUX_AB // A/B timing builds only: REDUX_DECODE_KERNEL=generic pins k_decode, =lock pins k_decode_lock
-    if (const char *force = getenv("REDUX_DECODE_KERNEL")) {
-        pair = false;
-        if (strcmp(force, "lock"))
-            lock = false;
-    }
+#ifdef REDUX_AB // A/B timing builds only: REDUX_DECODE_KERNEL=generic pins k_decode
+    if (getenv("REDUX_DECODE_KERNEL"))
+        lock = false;
 #endif
-    if (pair)
-        return p->code_bits == 32 ? DecKernel::PairCb32 : DecKernel::Pair;
     if (lock)
         return p->code_bits == 32 ? DecKernel::LockCb32 : DecKernel::Lock;
     if (g.u16)
@@ -287,11 +279,9 @@ const char *redux_decode_kernel_name(const redux_params *p, const void *d_out, u
 {
     if (check_params(p) != REDUX_OK || block_size == 0)
         return "";
+    (void)d_out; // every decoder takes any alignment (it only picks the store width inside the kernel)
     const Geometry g = geometry(p, block_size, block_size);
-    const bool aligned4 = (((uintptr_t)d_out) & 3) == 0 && (block_size & 3) == 0;
-    switch (pick_decode_kernel(g, p, aligned4)) {
-    case DecKernel::PairCb32: return "k_decode_pair<true> (u16 tree, core wave + aux wave per 64 blocks, code_bits 32)";
-    case DecKernel::Pair: return "k_decode_pair<false> (u16 tree, core wave + aux wave per 64 blocks)";
+    switch (pick_decode_kernel(g, p)) {
     case DecKernel::LockCb32: return "k_decode_lock<true> (u16 tree, one wave per 64 blocks, code_bits 32)";
     case DecKernel::Lock: return "k_decode_lock<false> (u16 tree, one wave per 64 blocks)";
     case DecKernel::GenericU16: return "k_decode<true, false> (u16 tree, per-lane control flow)";
@@ -517,7 +507,7 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
     const Geometry g = geometry(p, block_size, block_size);
     if (g.any)
         return (nblocks ? nblocks : 1) * g.tree_bytes;
-    return align_up((uint64_t)g.rc_n * 8, 256) + kClaimWords * 4; // reciprocal table, k_decode_pair's role book
+    return align_up((uint64_t)g.rc_n * 8, 256);
 }
 
 // d_in_used (optional, u64[nblocks]): bytes of each stream the reader fetched; only
@@ -576,13 +566,7 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         a.aligned4 = 2; // 16-byte aligned blocks: the lock-step decoder stages four dwords per store
     a.in_used    = (uint64_t *)d_in_used;
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
-    a.claims = (uint32_t *)((uint8_t *)d_workspace + align_up((uint64_t)g.rc_n * 8, 256));
-    const DecKernel which = pick_decode_kernel(g, p, a.aligned4 != 0);
-    if (which == DecKernel::PairCb32 || which == DecKernel::Pair)
-        HIP_TRY(hipMemsetAsync(a.claims, 0, kClaimWords * 4, s)); // empty role book
-    switch (which) {
-    case DecKernel::PairCb32: k_decode_pair<true><<<grid, 128, 0, s>>>(a); break;
-    case DecKernel::Pair: k_decode_pair<false><<<grid, 128, 0, s>>>(a); break;
+    switch (pick_decode_kernel(g, p)) {
     case DecKernel::LockCb32: k_decode_lock<true><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::Lock: k_decode_lock<false><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::GenericU16: k_decode<true, false><<<grid, 64, 0, s>>>(a); break;
@@ -596,12 +580,6 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     return REDUX_OK;
 }
 
-#ifdef REDUX_DP_STATS
-extern "C" int redux_debug_dp_stats(uint64_t *out8)
-{
-    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dp_stats), 64);
-}
-#endif
 #ifdef REDUX_DEC_CENSUS
 extern "C" int redux_debug_dec_census(uint32_t *out4096)
 {

@@ -894,10 +894,9 @@ def test_kernel_names_follow_the_dispatch(rx):
     assert enc((8, 30, 32), 4, 1 << 30, 65536).startswith("k_encode<true, false>")     # unaligned input
     assert enc((8, 30, 32), 0, 1 << 30, 1 << 20).startswith("k_encode<false, true>")    # u32 tree
     assert enc((12, 14, 16), 0, 1 << 20, 65536).startswith("k_encode_any")
-    assert dec((8, 30, 32), 65536).startswith("k_decode_pair<true>")
-    assert dec((8, 22, 24), 65536).startswith("k_decode_pair<false>")
-    assert dec((8, 30, 32), 65536, 2).startswith("k_decode_lock<true>")     # unaligned output
-    assert dec((8, 30, 32), 1001).startswith("k_decode_lock<true>")
+    assert dec((8, 30, 32), 65536).startswith("k_decode_lock<true>")
+    assert dec((8, 22, 24), 65536).startswith("k_decode_lock<false>")
+    assert dec((8, 30, 32), 1001, 2).startswith("k_decode_lock<true>")
     assert dec((8, 30, 32), 1 << 20).startswith("k_decode<false, true>")
     assert enc((8, 3, 32), 0, 1, 1) == ""
 
