@@ -352,6 +352,54 @@ __device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, 
     return f;
 }
 
+// The same descent under a STATIC model (redux_static.hpp): node i, i = 1..255, is the Fenwick form of the fixed
+// cumulative table -- cum[i] - cum[i - lowbit(i)], the total frequency of the symbols in [i - lowbit(i), i) -- as
+// u32, ONE table per workgroup shared by its lanes (nothing is ever updated).  The lanes of a wave read DIFFERENT
+// rows of it at the same column (a probe is node prefix + 2^b), so node i lives at dword i + (i >> 5): one pad
+// dword per 32 puts the 8 possible round-B rows and the 32 possible round-C rows in distinct banks instead of
+// one.  (On Zipf bytes it measures the same either way -- most lanes probe the same rows, which is a broadcast --
+// and SQ_LDS_BANK_CONFLICT reads 0 with the padding; uniform symbols are where the unpadded table would pay.)
+// cum256 = cum[256], the total of the data symbols (what tree[256] = count - 1 is to the adaptive model).
+__device__ __forceinline__ uint32_t dec_static_slot(uint32_t i) { return i + (i >> 5); }
+constexpr uint32_t kStaticTreeDwords = 272; // 256 + 8 pad dwords, rounded up to a 64-byte multiple
+
+__device__ __forceinline__ DecFound dec_search_static(const uint32_t *tab, const DecTop &T, uint32_t v, uint32_t cum256)
+{
+    uint32_t q = ~v, hq = q + cum256, bits = 0, q2;
+    DecFound f;
+    f.eofq = hq;
+#define REDUX_DEC_LEVEL(t)                                                                                             \
+    left = __builtin_uadd_overflow(q, (t), &q2);                                                                       \
+    bits = __builtin_amdgcn_alignbit(bits, q2, 31);                                                                    \
+    q    = q > q2 ? q : q2;                                                                                            \
+    hq   = hq < q2 ? hq : q2;
+    bool left;
+    REDUX_DEC_LEVEL(T.n128)
+    const uint32_t x6 = left ? T.n64 : T.n192, c5l = left ? T.n32 : T.n160, c5r = left ? T.n96 : T.n224;
+    REDUX_DEC_LEVEL(x6)
+    const uint32_t x5 = left ? c5l : c5r;
+    REDUX_DEC_LEVEL(x5)
+    const uint32_t *r = tab + (bits & 7u) * 33u; // prefix i = bits << 5 at dword i + (i >> 5)
+    const uint32_t w16 = r[16], w8 = r[8], w24 = r[24];
+    REDUX_DEC_LEVEL(w16)
+    const uint32_t x3 = left ? w8 : w24;
+    REDUX_DEC_LEVEL(x3)
+    const uint32_t  p5 = bits & 31u; // prefix i = p5 << 3: nodes i .. i+7 sit inside one block of 32
+    const uint32_t *r4 = tab + (p5 << 3) + (p5 >> 2);
+    const uint32_t  n1 = r4[1], n2 = r4[2], n3 = r4[3], n4 = r4[4], n5 = r4[5], n6 = r4[6], n7 = r4[7];
+    REDUX_DEC_LEVEL(n4)               // node i+4
+    const uint32_t e1  = left ? n2 : n6; // level 1: node i+2 or i+6
+    const uint32_t e0l = left ? n1 : n5, e0r = left ? n3 : n7; // level 0: i+1 / i+5 or i+3 / i+7
+    REDUX_DEC_LEVEL(e1)
+    const uint32_t x0 = left ? e0l : e0r;
+    REDUX_DEC_LEVEL(x0)
+#undef REDUX_DEC_LEVEL
+    f.s  = bits & 0xFFu;
+    f.lo = v + q + 1u;  // v - rem = cum[s]
+    f.hi = v + hq + 1u; // cum[s + 1]
+    return f;
+}
+
 // update(s+1) (adaptive_tree.rs:83-92): +1 on the levels where bit b of s is clear.  Levels 7-5
 // live in registers: node e of level b is incremented iff s lies in [e - 2^b, e), an unsigned
 // range compare + add-with-carry; levels 4-0 are fire-and-forget ds_add_u32.
@@ -493,16 +541,25 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
         dst[p] = (uint8_t)f.s;
 }
 
-template <bool CB32>
-__global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
+// STATIC: the model is a fixed table (redux_static.hpp): `lds` starts with its Fenwick form (256 dwords, shared
+// by the lanes) instead of 64 per-lane trees, nothing is updated, total frequency and reciprocal are constants.
+// Everything else -- code value, narrowing, renormalisation, bit reader, output staging, the careful per-lane
+// commit -- is the same code.
+template <bool CB32, bool STATIC>
+__device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds, const uint32_t *cum, double rc_static)
 {
-    __shared__ uint32_t lds[128 * 64 + 32 * 64]; // tree (32 KiB) + stream ring (8 KiB): four groups fill the CU's 160 KiB
+    constexpr uint32_t kModelBytes = STATIC ? kStaticTreeDwords * 4 : 128 * 64 * 4;
     const uint32_t lane = threadIdx.x;
     const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
     const bool     live = blk < a.nblocks;
 
-    for (uint32_t i = lane; i < 128 * 64 / 4; i += 64)
-        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    if (STATIC) {
+        for (uint32_t i = lane; i < 256; i += 64)
+            lds[dec_static_slot(i)] = i ? cum[i] - cum[i - (i & (0u - i))] : 0u;
+    } else {
+        for (uint32_t i = lane; i < 128 * 64 / 4; i += 64)
+            reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
     const uint32_t L = lane * 4u;
     uint32_t       A[8];
@@ -553,7 +610,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
     const uint32_t  rpo_last = has ? (uint32_t)(((((sp_abs + size + 3) & ~(uintptr_t)3) - (sp_abs & ~(uintptr_t)3)) >> 2) - 1) : 0u;
     const uint32_t  skip   = has ? (uint32_t)(sp_abs & 3) * 8 : 0u;
     auto rd = [&](uint32_t o) { return gin[o < rpo_last ? o : rpo_last]; };
-    constexpr uint32_t RB = 128 * 64 * 4;
+    constexpr uint32_t RB = kModelBytes;
     auto ring_write = [&](uint32_t chunk, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
         uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + RB + ((chunk & 7u) << 10) + L);
         q[0] = x0; q[64] = x1; q[128] = x2; q[192] = x3;
@@ -599,6 +656,16 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
     uint4    oq     = make_uint4(0, 0, 0, 0);
     uint32_t p      = 0;
     DecTop   T      = dec_top_new();
+    if (STATIC)
+        T = DecTop{lds[dec_static_slot(128)], lds[dec_static_slot(64)], lds[dec_static_slot(192)], lds[dec_static_slot(32)],
+                   lds[dec_static_slot(96)], lds[dec_static_slot(160)], lds[dec_static_slot(224)]};
+    const uint32_t cum256  = STATIC ? cum[256] : 0u;
+    const uint32_t c_const = STATIC ? cum[257] : 0u; // total_frequency() of the static model
+#ifdef REDUX_DEC_STAMPS
+#define REDUX_DEC_SEARCH(v_, c_) (STATIC ? dec_search_static(lds, T, v_, cum256) : dec_search(lds, L, T, v_, c_, dec_ts, dec_t0))
+#else
+#define REDUX_DEC_SEARCH(v_, c_) (STATIC ? dec_search_static(lds, T, v_, cum256) : dec_search(lds, L, T, v_, c_))
+#endif
 
 #define REDUX_DEC_READER                                                                                               \
     {                                                                                                                  \
@@ -662,7 +729,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
     // symbol.  A step is computed for all 64 lanes; if no lane is finished, reaches the EOF
     // symbol, collapses to low == high or runs out of stream (one v_or3 + one compare on sign
     // bits), it is committed without predication; otherwise the careful per-lane commit runs.
-    const uint32_t pfast = capn < nfreeze ? capn : nfreeze;
+    const uint32_t pfast = STATIC ? capn : (capn < nfreeze ? capn : nfreeze);
 #ifdef REDUX_DEC_CENSUS
     if (lane == 0 && blockIdx.x < 4096) {
         uint32_t hwid, xcc;
@@ -675,7 +742,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
     uint64_t dec_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dec_t0 = clock64();
 #endif
     if (aligned4) {
-        double cdm1 = 256.0, cd = 257.0;
+        double cdm1 = STATIC ? (double)(c_const - 1u) : 256.0, cd = STATIC ? (double)c_const : 257.0;
         // The group's four reciprocals are loaded a group ahead with VECTOR loads (every lane the
         // same 32 bytes), behind the ring's chunk request: their latency is covered by the one
         // vmcnt wait of the next group.  A scalar load would share lgkmcnt with the LDS, return
@@ -683,7 +750,7 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
         typedef double f64x4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) f64x4 *grc4;
         const grc4 rcv = (grc4)(uintptr_t)a.rc; // 256-byte aligned workspace, p a multiple of 4
-        f64x4      rcg = rcv[0], rcn;
+        f64x4      rcg = STATIC ? f64x4{rc_static, rc_static, rc_static, rc_static} : rcv[0], rcn;
         asm volatile("" : "+v"(rcg)); // arrived before the loop: no in-loop wait inherits this load
         for (; p + 4 <= pfast; p += 4) {
             if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
@@ -691,11 +758,11 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
             REDUX_DEC_REQUEST
-            rcn = rcv[(p >> 2) + 1]; // the table has 32 entries of slack (geometry())
+            rcn = STATIC ? rcg : rcv[(p >> 2) + 1]; // the table has 32 entries of slack (geometry())
 #pragma unroll
             for (int K = 0; K < 4; K++) {
                 const double   rc = rcg[K];
-                const uint32_t c  = 257u + p + K;
+                const uint32_t c  = STATIC ? c_const : 257u + p + K;
 #if REDUX_DEC_DUP == 6 // what the bit reader costs: the same instructions once more on copies
                 {
                     uint64_t bb = S.bbits; uint32_t bc = S.bcnt, rp2 = rpo, fe = fetched;
@@ -726,12 +793,12 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
 #if REDUX_DEC_DUP == 2
                 uint32_t v_ = v;
                 {
-                    const DecFound f0 = dec_search(lds, L, T, v, c DEC_STAMP_PASS);
+                    const DecFound f0 = REDUX_DEC_SEARCH(v, c);
                     asm volatile("" : "+v"(v_) : "v"(f0.s), "v"(f0.lo), "v"(f0.hi));
                 }
-                const DecFound f = dec_search(lds, L, T, v_, c DEC_STAMP_PASS);
+                const DecFound f = REDUX_DEC_SEARCH(v_, c);
 #else
-                const DecFound f   = dec_search(lds, L, T, v, c DEC_STAMP_PASS);
+                const DecFound f   = REDUX_DEC_SEARCH(v, c);
 #endif
                 // narrowing + renormalisation (codec.rs:133-161), all lanes
                 const double   Y      = __builtin_fma(R1d, rc, rc);
@@ -794,7 +861,8 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
                         asm volatile("" ::"v"(T2.n128), "v"(T2.n64), "v"(T2.n192), "v"(T2.n32), "v"(T2.n96), "v"(T2.n160), "v"(T2.n224));
                     }
 #endif
-                    dec_update(lds, A, T, f.s);
+                    if (!STATIC)
+                        dec_update(lds, A, T, f.s);
                     S.low      = (low2 << j) & 0x7FFFFFFFu;
                     S.ihigh    = (ih2 << j) & 0x7FFFFFFFu;
                     S.consumed = cons2;
@@ -807,10 +875,12 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
                     S.bcnt -= n;
                     S.obuf |= f.s << (8 * K);
                 } else {
-                    dec_commit_careful<CB32>(S, T, f, lds, A, R1, R1d, rc, c, sh, stream_bits, p + K, true, true, true, dst);
+                    dec_commit_careful<CB32>(S, T, f, lds, A, R1, R1d, rc, c, sh, stream_bits, p + K, !STATIC, true, true, dst);
                 }
-                cdm1 = cd;
-                cd += 1.0;
+                if (!STATIC) {
+                    cdm1 = cd;
+                    cd += 1.0;
+                }
                 DEC_STAMP(6, S.low + S.W)
             }
             rcg = rcn;
@@ -826,8 +896,8 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
         if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
             break;
         const uint32_t nup = p < nfreeze ? p : nfreeze;
-        const double   rc  = rcp[nup];
-        const uint32_t c   = 257u + nup;
+        const double   rc  = STATIC ? rc_static : rcp[nup];
+        const uint32_t c   = STATIC ? c_const : 257u + nup;
         if ((p & 3) == 0) {
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
@@ -838,13 +908,14 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
         const uint32_t Vd  = (S.W - S.low) >> sh;
         const double   R1d = (double)R1;
         const uint32_t v   = dec_value(R1d, Vd, (double)c, (double)(c - 1u));
-        const DecFound f   = dec_search(lds, L, T, v, c DEC_STAMP_PASS);
-        dec_commit_careful<CB32>(S, T, f, lds, A, R1, R1d, rc, c, sh, stream_bits, p, p < nfreeze, p < capn, aligned4, dst);
+        const DecFound f   = REDUX_DEC_SEARCH(v, c);
+        dec_commit_careful<CB32>(S, T, f, lds, A, R1, R1d, rc, c, sh, stream_bits, p, !STATIC && p < nfreeze, p < capn, aligned4, dst);
     }
 #undef REDUX_DEC_READER
 #undef REDUX_DEC_RETIRE
 #undef REDUX_DEC_STORE
 #undef REDUX_DEC_REQUEST
+#undef REDUX_DEC_SEARCH
     if (live) {
         if (aligned4) {
             // the 0..3 staged dwords (oldest first: the last k components of oq), then the partial one
@@ -865,6 +936,13 @@ __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
             a.in_used[blk]      = used < size ? used : size;
         }
     }
+}
+
+template <bool CB32>
+__global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
+{
+    __shared__ uint32_t lds[128 * 64 + 32 * 64]; // tree (32 KiB) + stream ring (8 KiB): four groups fill the CU's 160 KiB
+    decode_lock_body<CB32, false>(a, lds, nullptr, 0.0);
 }
 
 } // namespace redux

@@ -202,6 +202,20 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
         }                                                                                              \
     } while (0)
 
+static uint32_t cu_count()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0)
+            cus = 256;
+    }
+    return (uint32_t)cus;
+}
+
 // ---- which kernel a call runs: ONE decision, used by the launch code and reported by
 // redux_encode_kernel_name / redux_decode_kernel_name (bench.py's roofline.kernel) ------------
 enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Any };
@@ -756,8 +770,11 @@ int redux_static_encode_blocks_dev(const redux_params *p, const uint32_t *cum, c
     a.aligned16  = ((((uintptr_t)d_in) & 15) == 0 && (block_size & 15) == 0) ? 1 : 0;
     memcpy(a.tab.cum, cum, sizeof a.tab.cum);
     const uint32_t grid = (uint32_t)((g.nblocks + 63) / 64);
+    const bool     solo = grid <= 4u * cu_count(); // as k_decode_static_lock: one wave per SIMD, not two on some
     if (cum[kStaticEntries - 1] >= (1u << 17))
         k_encode_static<true, false><<<grid, 64, 0, s>>>(a);
+    else if (p->code_bits == 32 && solo)
+        k_encode_static<false, true, true><<<grid, 64, 0, s>>>(a);
     else if (p->code_bits == 32)
         k_encode_static<false, true><<<grid, 64, 0, s>>>(a);
     else
@@ -796,8 +813,38 @@ int redux_static_decode_blocks_dev(const redux_params *p, const uint32_t *cum, c
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
     if (cum[kStaticEntries - 1] >= (1u << 17))
         k_decode_static<true><<<grid, 64, 0, s>>>(a);
-    else
-        k_decode_static<false><<<grid, 64, 0, s>>>(a);
+    else {
+        StaticLockArgs la;
+        memset(&la, 0, sizeof la);
+        la.d.in         = a.in;
+        la.d.in_offsets = a.in_offsets;
+        la.d.nblocks    = nblocks;
+        la.d.out        = a.out;
+        la.d.out_sizes  = a.out_sizes;
+        la.d.status     = a.status;
+        la.d.rc         = nullptr;
+        la.d.block_size = block_size;
+        la.d.nfreeze    = 0xFFFFFFFFu;
+        la.d.code_bits  = p->code_bits;
+        la.d.aligned4   = a.aligned4;
+        if (a.aligned4 && (((uintptr_t)d_out) & 15) == 0 && (block_size & 15) == 0)
+            la.d.aligned4 = 2;
+        la.d.in_used    = nullptr;
+        la.rc           = a.rc;
+        la.tab          = a.tab;
+        const bool solo = grid <= 4u * cu_count(); // at most one wave per SIMD: keep the dispatcher from doubling them up
+        if (p->code_bits == 32) {
+            if (solo)
+                k_decode_static_lock<true, true><<<grid, 64, 0, s>>>(la);
+            else
+                k_decode_static_lock<true, false><<<grid, 64, 0, s>>>(la);
+        } else {
+            if (solo)
+                k_decode_static_lock<false, true><<<grid, 64, 0, s>>>(la);
+            else
+                k_decode_static_lock<false, false><<<grid, 64, 0, s>>>(la);
+        }
+    }
     if (d_summary)
         k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
     HIP_TRY(hipGetLastError());

@@ -10,7 +10,8 @@
 // search of the table.  oracle/ has the same model (OX_MODEL_STATIC, StaticModel).
 //
 //   k_encode_static<FIXUP>   one lane per block, 64 blocks per wave, table in LDS (1 KiB)
-//   k_decode_static<FIXUP>   the inverse
+//   k_decode_static<FIXUP>   the inverse, per-lane control flow (totals >= 2^17)
+//   k_decode_static_lock     the inverse in lock-step form (totals < 2^17: the default)
 //
 // These share every building block with the adaptive kernels (EncState, encode_symbol,
 // encode_finish, BitIn, scale_div); what they do not have is a tree, so a workgroup needs 1 KiB
@@ -82,10 +83,14 @@ __device__ __forceinline__ void static_chunk(EncState &S, const uint32_t *tab, c
     }
 }
 
-template <bool FIXUP, bool CB32>
+template <bool SOLO>
+__device__ __forceinline__ void claim_the_simd();
+
+template <bool FIXUP, bool CB32, bool SOLO = false>
 __global__ void __launch_bounds__(64) k_encode_static(StaticEncArgs a)
 {
     __shared__ uint32_t tab[kStaticEntries + 2];
+    claim_the_simd<SOLO>();
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < kStaticEntries; i += 64)
         tab[i] = a.tab.cum[i];
@@ -277,6 +282,38 @@ __global__ void __launch_bounds__(64) k_decode_static(StaticDecArgs a)
         a.out_sizes[blk] = n_out;
         a.status[blk]    = st;
     }
+}
+
+// The static decoder in k_decode_lock's form (redux_decode.hpp, decode_lock_body<CB32, true>): all 64 lanes in
+// lock-step, the table as its Fenwick form in LDS (1 KiB per workgroup, shared by the lanes), get_symbol as the
+// same carry-driven descent with speculative loads (two LDS round trips instead of nine dependent ones), stream
+// ring, staged 16-byte output stores, one ballot per step.  For total < 2^17 (no quotient fix-up, as the adaptive
+// lock-step decoder); larger totals keep k_decode_static<true>.
+struct StaticLockArgs {
+    DecArgs     d;
+    double      rc;
+    StaticTable tab;
+};
+
+// SOLO: the kernel claims more than half of a SIMD's 512 registers, so that no two of its waves share a SIMD.
+// A lock-step wave that has a SIMD to itself finishes a 64 KiB block in ~20 ms; the dispatcher, free to pack
+// (81 registers, 9 KiB of LDS), puts two waves on some SIMDs and none on others when the grid is only four waves
+// per CU, and the kernel then lasts as long as the doubled-up ones (32.3 ms; SQ_WAVE_CYCLES says the average wave
+// lived 0.74 of that).  k_decode_lock is safe from this by accident of its register allocation (257).  Used for
+// grids of at most one wave per SIMD; larger grids want several waves per SIMD (4: 237 GB/s at 16 KiB blocks).
+template <bool SOLO>
+__device__ __forceinline__ void claim_the_simd()
+{
+    if (SOLO)
+        asm volatile("" ::: "a255");
+}
+
+template <bool CB32, bool SOLO>
+__global__ void __launch_bounds__(64) k_decode_static_lock(StaticLockArgs a)
+{
+    __shared__ uint32_t lds[kStaticTreeDwords + 32 * 64]; // Fenwick form of the table (~1 KiB, padded) + stream ring (8 KiB)
+    claim_the_simd<SOLO>();
+    decode_lock_body<CB32, true>(a.d, lds, a.tab.cum, a.rc);
 }
 
 } // namespace redux

@@ -8,14 +8,24 @@ import redux_amd as rx
 from redux_amd import _lib
 
 nblocks = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+static = len(sys.argv) > 2 and sys.argv[2] == "static"  # the static-table decoder (same body) on Zipf bytes
 B = 65536
 n = nblocks * B
-d_in = rx.gen_iid(n, 0x5EED0001, 0, device="cuda:0")
-enc = rx.DeviceEncoder((8, 30, 32), B, n, device="cuda:0")
+if static:
+    import numpy as np
+    d_in = rx.gen_zipf(n)
+    hist = torch.bincount(d_in[: 1 << 24].to(torch.int64), minlength=256).cpu().numpy().astype(np.float64)
+    f = np.maximum(1, np.floor(hist / hist.sum() * 65000)).astype(np.int64)
+    cum = [0] + list(np.cumsum(np.append(f, 1)))
+    enc = rx.DeviceStaticCoder((8, 30, 32), cum, B, n)
+    dec = enc
+else:
+    d_in = rx.gen_iid(n, 0x5EED0001, 0, device="cuda:0")
+    enc = rx.DeviceEncoder((8, 30, 32), B, n, device="cuda:0")
+    dec = rx.DeviceDecoder((8, 30, 32), B, nblocks, device="cuda:0")
 enc.encode(d_in)
 torch.cuda.synchronize()
 out_bytes = int(enc.offsets[nblocks].item())
-dec = rx.DeviceDecoder((8, 30, 32), B, nblocks, device="cuda:0")
 dec.decode(enc.out[:out_bytes], enc.offsets[: nblocks + 1])
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -23,10 +23,12 @@ for _ in range(2):
     out, offs, st, summ = coder.encode(d_in)
 torch.cuda.synchronize()
 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+total = int(offs[nb].item())
+coder.decode(out[:total], offs)  # first launch of the decode kernel: code object load
+torch.cuda.synchronize()
 e0.record()
 out, offs, st, summ = coder.encode(d_in)
 e1.record()
-total = int(offs[nb].item())
 d_out, sizes, dst, dsum = coder.decode(out[:total], offs)
 e2.record()
 torch.cuda.synchronize()
