@@ -9,5 +9,6 @@ timeout -k 10 300 python tools/measure_extra.py > $OUT/extra.log 2>&1 && tail -1
 timeout -k 10 600 bash tools/prof.sh $TAG > $OUT/prof.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/prof_$TAG > $OUT/prof_summary.txt 2>&1
 timeout -k 10 400 bash tools/prof_decode.sh dec_$TAG > $OUT/prof_decode.txt 2>&1
+WORKLOAD=zipf timeout -k 10 400 bash tools/prof_traffic.sh zipf_$TAG > $OUT/prof_traffic_zipf.txt 2>&1
 cp $(ls -t gpurun_out/prof_$TAG/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 echo done
