@@ -1,0 +1,335 @@
+// redux_gen.hpp -- the lock-step block coder for the OTHER symbol widths the reference tests
+// (src/model/tests.rs:95-251: 4- and 12-bit symbols), code_bits <= 32 (gfx950 only).  SURVEY section 8(f).3.
+//
+// redux_any.hpp covers every Parameters triple as a one-lane-per-block rendering of the reference's loops.  For
+// symbol_bits 4 and 12 this file is the MI355X form of the same functions, built like the 8-bit kernels:
+//   * one LANE per block, 64 blocks per wave, all lanes on the same symbol index, so the model's total
+//     (2^symbol_bits + 1 + symbols coded, until the freq_max freeze: adaptive_tree.rs:84) is WAVE-UNIFORM and the two
+//     u64 divisions of codec.rs:59-60 are multiplications by a per-step reciprocal (scale_div<FIXUP = true>: a block
+//     of 4-bit symbols passes count 2^17);
+//   * the Fenwick tree as u32 increments d[i] = tree[i] - lowbit(i), i = 1 .. 2^symbol_bits - 1, in per-lane
+//     columns: row e of lane l at e * 256 + 4 l.  4-bit symbols: 16 rows = 4 KiB of LDS per wave.  12-bit symbols:
+//     4096 rows = 1 MiB per wave in the workspace (global atomics; the rows a wave touches in one step are 12
+//     independent requests per lane, issued back to back; the tree of a small grid stays in L2);
+//   * get_frequency = one fetch-add per level (addend 1 where update(s+1) increments the node, 0 where the prefix
+//     sums only read it) + two masked sums (adaptive_tree.rs:63-92), closed-form renormalisation and bit output
+//     exactly as encode_symbol (redux_coder.hpp); the decoder's descent probes the same nodes (adaptive_tree.rs:115-136);
+//   * symbols are read_bits(symbol_bits) MSB-first (bitio/mod.rs:78-120): two per byte, or two per three bytes; a
+//     trailing partial symbol is dropped and the block ends (Err(Eof) -> EOF symbol, codec.rs:108); the decoder writes
+//     write_bits(symbol, symbol_bits) and never flushes a partial byte (lib.rs:113-120).
+// Everything is predicated per lane (ragged blocks, errors): this path is about being a designed kernel instead of a
+// port, not about the last instruction; the 8-bit kernels are the tuned ones.
+//
+// Included by redux_hip.hip (one translation unit).
+#pragma once
+
+#include "redux_coder.hpp"
+#include "redux_decode.hpp" // BitIn
+#include "redux_encode.hpp" // wave_max
+
+#include "../../include/redux_hip.h"
+
+namespace redux {
+
+template <int SB>
+struct GenTree {
+    static constexpr bool     kLds   = SB <= 8;
+    static constexpr uint32_t kRows  = 1u << SB;
+    static constexpr uint32_t kMask  = kRows - 1u;
+    static constexpr uint64_t kBytes = (uint64_t)kRows * 256; // per wave of 64 blocks
+
+    uint32_t *base; // row e of this lane: base[e * 64]  (base already points at the lane's column)
+
+    __device__ __forceinline__ uint32_t fetch_add(uint32_t e, uint32_t v) const
+    {
+        if (kLds)
+            return __hip_atomic_fetch_add(base + e * 64u, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __hip_atomic_fetch_add(base + e * 64u, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ uint32_t load(uint32_t e) const { return base[e * 64u]; }
+
+    // get_frequency(s) for a data symbol (adaptive_tree.rs:105-113); nup = updates so far, upd = the model is not frozen
+    __device__ __forceinline__ void get_frequency(uint32_t s, uint32_t nup, bool upd, uint32_t &lo, uint32_t &hi) const
+    {
+        uint32_t       x[SB];
+        const uint32_t m = s + 1;
+#pragma unroll
+        for (int b = 0; b < SB; b++) {
+            const uint32_t e = (s | (1u << b)) & (kMask << b); // the one node of level b on s's root path
+            x[b]             = fetch_add(e, (upd && !((s >> b) & 1u)) ? 1u : 0u);
+        }
+        uint32_t ls = s, hs = m;
+#pragma unroll
+        for (int b = 0; b < SB; b++) {
+            ls += ((s >> b) & 1u) ? x[b] : 0u;
+            hs += ((m >> b) & 1u) ? x[b] : 0u;
+        }
+        lo = ls;
+        hi = hs + (m >> SB) * nup; // s + 1 == 2^SB selects the derived node 2^SB = 2^SB + #updates
+    }
+};
+
+// symbol k of a block of `len` bytes at src: read_bits(SB) MSB-first
+template <int SB>
+__device__ __forceinline__ uint32_t gen_symbol(const uint8_t *src, uint32_t k)
+{
+    if (SB == 4) {
+        const uint32_t byte = src[k >> 1];
+        return (k & 1u) ? (byte & 15u) : (byte >> 4);
+    } else { // SB == 12: symbols 2j, 2j+1 share bytes 3j .. 3j+2
+        const uint32_t i  = k + (k >> 1);
+        const uint32_t b0 = src[i], b1 = src[i + 1];
+        return (k & 1u) ? (((b0 & 15u) << 8) | b1) : ((b0 << 4) | (b1 >> 4));
+    }
+}
+
+struct GenEncArgs {
+    const uint8_t *in;
+    uint64_t       in_len;
+    uint64_t       nblocks;
+    uint8_t       *slots;
+    uint64_t       slot_bytes;
+    uint32_t      *sizes;
+    int32_t       *status;
+    const double  *rc;       // rc[i] = 1 / (2^SB + 1 + i), bumped (k_fill_rc_from)
+    uint32_t      *trees;    // SB 12: kRows * 64 u32 per wave, zero at launch
+    uint32_t       block_size;
+    uint32_t       slot_cap;
+    uint32_t       nfreeze;  // freq_max - (2^SB + 1): updates before the freeze
+    uint32_t       code_bits;
+};
+
+__global__ void k_fill_rc_from(double *rc, uint32_t n, uint32_t first)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double r = 1.0 / (double)(first + i); // correctly rounded, then biased up 4 ulp as k_fill_rc (scale_div)
+        rc[i]          = __longlong_as_double(__double_as_longlong(r) + 4);
+    }
+}
+
+template <int SB>
+__global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
+{
+    typedef GenTree<SB> Tree;
+    __shared__ uint32_t lds[Tree::kLds ? Tree::kRows * 64 : 64];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t blk0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t blk  = blk0 + lane;
+    const bool     live = blk < a.nblocks;
+    if (Tree::kLds) {
+        for (uint32_t i = lane; i < Tree::kRows * 64; i += 64)
+            lds[i] = 0;
+        __syncthreads();
+    }
+    Tree T;
+    T.base = (Tree::kLds ? lds : a.trees + (uint64_t)blockIdx.x * Tree::kRows * 64) + lane;
+
+    uint32_t len = 0;
+    if (live) {
+        const uint64_t rem = a.in_len - blk * a.block_size;
+        len                = rem < a.block_size ? (uint32_t)rem : a.block_size;
+    }
+    const uint32_t nsym   = (uint32_t)(((uint64_t)len * 8) / SB); // whole symbols; trailing bits are dropped (codec.rs:108)
+    const uint8_t *src    = a.in + (live ? blk : blk0) * (uint64_t)a.block_size;
+    uint8_t       *wdst   = a.slots + blk0 * a.slot_bytes;
+    const uint32_t off0   = live ? lane * (uint32_t)a.slot_bytes : (uint32_t)(a.nblocks - blk0) * (uint32_t)a.slot_bytes;
+    const uint32_t limit  = off0 + a.slot_cap;
+    const uint32_t maxsym = __builtin_amdgcn_readfirstlane(wave_max(live ? nsym : 0u));
+    const uint32_t sh     = 32 - a.code_bits;
+    const uint32_t nfreeze = a.nfreeze;
+    const rc_ptr   rc     = (rc_ptr)a.rc;
+    constexpr uint32_t kCount0 = (1u << SB) + 1u;
+
+    EncState S;
+    enc_init(S, off0);
+    for (uint32_t p = 0; p <= maxsym; p++) {
+        const uint32_t nup = p < nfreeze ? p : nfreeze; // wave-uniform
+        const double   r   = rc[nup];
+        const uint32_t c   = kCount0 + nup;
+        if (live && p < nsym) {
+            uint32_t lo, hi;
+            T.get_frequency(gen_symbol<SB>(src, p), nup, p < nfreeze, lo, hi);
+            encode_symbol<true>(S, lo, hi, c, r, sh, false, wdst, limit);
+        } else if (live && p == nsym) {
+            // EOF symbol (codec.rs:108): cum(2^SB) = count - 1, cum(2^SB + 1) = count
+            const uint32_t shifts = encode_symbol<true>(S, c - 1, c, c, r, sh, true, wdst, limit);
+            const uint32_t size   = encode_finish(S, shifts, a.code_bits, off0, wdst, limit);
+            a.sizes[blk]  = size;
+            a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+        }
+    }
+}
+
+struct GenDecArgs {
+    const uint8_t  *in;
+    const uint64_t *in_offsets; // nblocks + 1
+    uint64_t        nblocks;
+    uint8_t        *out;        // block b at out + b*block_size
+    uint32_t       *out_sizes;
+    int32_t        *status;
+    const double   *rc;
+    uint32_t       *trees;      // SB 12
+    uint64_t       *in_used;    // optional
+    uint32_t        block_size;
+    uint32_t        nfreeze;
+    uint32_t        code_bits;
+};
+
+template <int SB>
+__global__ void __launch_bounds__(64) k_decode_gen(GenDecArgs a)
+{
+    typedef GenTree<SB> Tree;
+    __shared__ uint32_t lds[Tree::kLds ? Tree::kRows * 64 : 64];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
+    const bool     live = blk < a.nblocks;
+    if (Tree::kLds) {
+        for (uint32_t i = lane; i < Tree::kRows * 64; i += 64)
+            lds[i] = 0;
+        __syncthreads();
+    }
+    Tree T;
+    T.base = (Tree::kLds ? lds : a.trees + (uint64_t)blockIdx.x * Tree::kRows * 64) + lane;
+
+    const uint32_t cb = a.code_bits, sh = 32 - cb;
+    uint64_t       size = 0;
+    const uint8_t *sp   = a.in;
+    if (live) {
+        const uint64_t o0 = a.in_offsets[blk];
+        size              = a.in_offsets[blk + 1] - o0;
+        sp                = a.in + o0;
+    }
+    const uint64_t stream_bits = size * 8;
+    uint8_t       *dst         = a.out + (live ? blk : 0) * (uint64_t)a.block_size;
+    const uint32_t capn        = a.block_size; // bytes
+    const rc_ptr   rcp         = (rc_ptr)a.rc;
+    constexpr uint32_t kCount0 = (1u << SB) + 1u;
+
+    BitIn B;
+    B.init(sp, live ? size : 0);
+    uint32_t W        = B.take(cb) << sh; // codec.rs:124-127
+    uint64_t consumed = cb;
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    int32_t  st   = REDUX_OK;
+    bool     done = !live;
+    if (live && consumed > stream_bits) {
+        st   = REDUX_EOF;
+        done = true;
+    }
+    uint64_t obits = 0; // bits handed to write_bits so far (bitio/mod.rs:148-181): bytes [0, obits / 8) are in dst
+    uint32_t oacc  = 0; // the incomplete byte's bits, right-aligned
+    for (uint32_t p = 0;; p++) {
+        if (__builtin_amdgcn_readfirstlane(__ballot(!done) == 0))
+            break;
+        const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
+        const double   rc  = rcp[nup];
+        const uint32_t c   = kCount0 + nup;
+        if (!done) {
+            // value = ((pending - low + 1) * count - 1) / range      (codec.rs:129-131)
+            const uint32_t R1  = (high - low) >> sh;
+            const uint32_t Vd  = (W - low) >> sh;
+            const uint64_t num = ((uint64_t)Vd + 1) * c - 1;
+            const double   xd  = (double)R1 + 1.0;
+            uint32_t       v   = (uint32_t)((double)num / xd);
+            {
+                const int64_t r = (int64_t)(num - ((uint64_t)v * R1 + v));
+                if (r < 0)
+                    v--;
+                else if ((uint64_t)r > (uint64_t)R1)
+                    v++;
+            }
+            uint32_t lo, hi, s = 0;
+            bool     is_eof = false;
+            if (v >= c - 1) { // first probe of get_symbol: tree[2^SB] = 2^SB + #updates = count - 1 (adaptive_tree.rs:116)
+                is_eof = true;
+                lo     = c - 1;
+                hi     = c;
+            } else {
+                uint32_t x[SB], ea[SB];
+                uint32_t i = 0, rem = v;
+#pragma unroll
+                for (int b = SB - 1; b >= 0; b--) {
+                    ea[b] = i | (1u << b);
+                    x[b]  = T.load(ea[b]);
+                    const uint32_t tv = (1u << b) + x[b];
+                    if (rem >= tv) {
+                        i |= 1u << b;
+                        rem -= tv;
+                    }
+                }
+                s  = i;
+                lo = v - rem;
+                const uint32_t m  = s + 1;
+                uint32_t       hs = m;
+#pragma unroll
+                for (int b = 0; b < SB; b++)
+                    hs += ((m >> b) & 1u) ? x[b] : 0u;
+                hi = hs + (s == Tree::kMask ? nup : 0u);
+                if (p < a.nfreeze) {
+#pragma unroll
+                    for (int b = 0; b < SB; b++)
+                        if (!((s >> b) & 1u))
+                            T.fetch_add(ea[b], 1u);
+                }
+            }
+            if (is_eof) { // codec.rs:136-138: returns before any renormalisation
+                done = true;
+            } else {
+                const double   Y     = __builtin_fma((double)R1, rc, rc);
+                const uint32_t nlow  = low + (scale_div<true>(R1, Y, lo, c) << sh);
+                const uint32_t nhigh = low + (scale_div<true>(R1, Y, hi, c) << sh) - 1u;
+                const uint32_t xx    = nlow ^ nhigh;
+                const uint32_t k     = xx ? (uint32_t)__builtin_clz(xx) : 32u;
+                const uint32_t low2  = (uint32_t)((uint64_t)nlow << k);
+                const uint32_t ih2   = (uint32_t)((uint64_t)(~nhigh) << k);
+                const uint32_t t     = (low2 & ih2) << 1;
+                const uint32_t j     = (uint32_t)__builtin_clz(~t);
+                low                  = (low2 << j) & 0x7FFFFFFFu;
+                high                 = ~((ih2 << j) & 0x7FFFFFFFu);
+                const uint32_t n     = k + j; // bits pulled by get_bit (codec.rs:157)
+                consumed += n;
+                if (consumed > stream_bits) { // read_bits would hit Err(Eof) (bitio/mod.rs:107)
+                    st   = REDUX_EOF;
+                    done = true;
+                } else {
+                    const uint32_t nb   = B.take(n);
+                    const uint64_t comb = ((uint64_t)W << 32) | ((uint64_t)nb << (32 + sh - n));
+                    const uint64_t c1   = comb << k;
+                    const uint64_t c2   = c1 << j;
+                    W = (((uint32_t)(c2 >> 32) & 0x7FFFFFFFu) | ((uint32_t)(c1 >> 32) & 0x80000000u)) &
+                        (0xFFFFFFFFu << sh);
+                    // write_bits(symbol, SB) (codec.rs:171): bytes leave as they complete; the first one past the
+                    // block's capacity is where the writer fails
+                    uint32_t acc  = (oacc << SB) | s;
+                    uint32_t have = (uint32_t)(obits & 7u) + SB;
+                    uint64_t pos  = obits >> 3;
+                    while (have >= 8 && !done) {
+                        if (pos >= capn) {
+                            st   = REDUX_OUTPUT_TOO_SMALL;
+                            done = true;
+                        } else {
+                            have -= 8;
+                            dst[pos++] = (uint8_t)(acc >> have);
+                        }
+                    }
+                    if (!done) {
+                        oacc = acc & ((1u << have) - 1u);
+                        obits += SB;
+                    } else
+                        obits = pos * 8; // the bytes before the failing one are written
+                }
+            }
+        }
+    }
+    if (live) {
+        a.out_sizes[blk] = (uint32_t)(obits >> 3); // a partial byte is never flushed (lib.rs:113-120)
+        a.status[blk]    = st;
+        if (a.in_used) { // the reader fetches whole bytes, and never past the end of the stream
+            const uint64_t used = (consumed + 7) / 8;
+            a.in_used[blk]      = used < size ? used : size;
+        }
+    }
+}
+
+} // namespace redux

@@ -6,6 +6,7 @@
 //   redux_decode.hpp   k_decode, k_decode_lock (default decoder)
 //   redux_pack.hpp     k_scan_sizes, k_compact: slots -> dense stream + offsets
 //   redux_any.hpp      general Parameters (symbol_bits <= 16, code_bits <= 63), one lane per block
+//   redux_gen.hpp      k_encode_gen / k_decode_gen: 4- and 12-bit symbols (code_bits <= 32) in lock-step form
 //   redux_synth.hpp    k_gen_iid / k_gen_zipf
 //   redux_static.hpp   k_encode_static / k_decode_static: the coder core under a fixed frequency table
 // This file holds the general-parameter kernels' launch shims, the workspace geometry and the
@@ -14,6 +15,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC redux_hip.hip -o libredux_hip.so
 #include "redux_coder.hpp"
 #include "redux_any.hpp"
+#include "redux_gen.hpp"
 #include "redux_encode.hpp"
 #include "redux_decode.hpp"
 #include "redux_pack.hpp"
@@ -106,7 +108,8 @@ struct Geometry {
     uint32_t nfreeze;
     bool     u16, fixup;
     bool     any;        // general-parameter path (redux_any.hpp): symbol_bits != 8 or code_bits > 32
-    uint64_t tree_bytes; // any: per-block tree in the workspace
+    bool     gen;        // ... except 4- and 12-bit symbols with code_bits <= 32: lock-step kernels of redux_gen.hpp
+    uint64_t tree_bytes; // any / gen (12-bit symbols): per-block tree in the workspace
     // workspace layout (encode)
     uint64_t off_rc, off_sizes, off_mode, off_slots, off_trees, total;
 };
@@ -124,6 +127,11 @@ static int check_params(const redux_params *p)
 }
 
 static bool is_any(const redux_params *p) { return p->symbol_bits != 8 || p->code_bits > 32; }
+// the widths src/model/tests.rs exercises besides 8: lock-step kernels (symbol index and byte offsets stay in 32 bits)
+static bool is_gen(const redux_params *p, uint32_t block_size)
+{
+    return (p->symbol_bits == 4 || p->symbol_bits == 12) && p->code_bits <= 32 && block_size < (1u << 28);
+}
 
 static uint64_t slot_cap_for(const redux_params *p, uint32_t block_size)
 {
@@ -176,6 +184,18 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.any = !static_model && is_any(p);
     if (static_model)
         g.rc_n = 0;
+    g.gen = !static_model && is_gen(p, block_size);
+    if (g.gen) { // reciprocal table over the symbol count; 12-bit symbols: 4096 u32 rows x 64 lanes per wave in the workspace
+        const uint64_t k0      = (1ull << p->symbol_bits) + 1;
+        const uint64_t nsym    = maxlen * 8 / p->symbol_bits;
+        const uint64_t nfreeze = freq_max - k0;
+        g.any     = false;
+        g.nfreeze = (uint32_t)(nfreeze < 0xFFFFFFFFull ? nfreeze : 0xFFFFFFFFull);
+        g.rc_n    = (uint32_t)((nsym < nfreeze ? nsym : nfreeze) + 1 + 32);
+        g.u16     = false;
+        g.fixup   = true;
+        g.tree_bytes = p->symbol_bits == 12 ? GenTree<12>::kBytes / 64 : 0;
+    }
     if (g.any) { // no reciprocal table; one tree of 2^symbol_bits + 2 u32 per block
         g.rc_n       = 0;
         g.u16        = false;
@@ -188,7 +208,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.off_slots = g.off_mode + 256 + kClaimWords * 4; // mode word, then k_encode_pair's role book
     // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode
     g.off_trees = align_up(g.off_slots + ((g.nblocks + 63) / 64 * 64 + 1) * g.slot_bytes + (g.nblocks + 63) / 64 * 128, 256);
-    g.total     = g.off_trees + g.nblocks * g.tree_bytes;
+    g.total     = g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes; // gen: whole waves
     return g;
 }
 
@@ -218,8 +238,8 @@ static uint32_t cu_count()
 
 // ---- which kernel a call runs: ONE decision, used by the launch code and reported by
 // redux_encode_kernel_name / redux_decode_kernel_name (bench.py's roofline.kernel) ------------
-enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Any };
-enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Any };
+enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Gen4, Gen12, Any };
+enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Gen4, Gen12, Any };
 
 // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset; otherwise
 // (giant blocks, whole-stream mode) one block per wave.
@@ -230,6 +250,8 @@ static uint32_t encode_lanes(const Geometry &g, uint32_t block_size)
 
 static EncKernel pick_encode_kernel(const Geometry &g, const redux_params *p, bool aligned16, uint32_t block_size)
 {
+    if (g.gen)
+        return p->symbol_bits == 4 ? EncKernel::Gen4 : EncKernel::Gen12;
     if (g.any)
         return EncKernel::Any;
     bool pair = g.u16 && aligned16 && encode_lanes(g, block_size) == 64;
@@ -248,6 +270,8 @@ static EncKernel pick_encode_kernel(const Geometry &g, const redux_params *p, bo
 
 static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p)
 {
+    if (g.gen)
+        return p->symbol_bits == 4 ? DecKernel::Gen4 : DecKernel::Gen12;
     if (g.any)
         return DecKernel::Any;
     bool lock = g.u16 && !g.fixup;
@@ -284,6 +308,8 @@ const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, ui
     case EncKernel::SingleU16: return "k_encode<true, false> (u16 tree, one wave per 64 blocks)";
     case EncKernel::SingleU16Fixup: return "k_encode<true, true> (u16 tree, one wave per 64 blocks, quotient fix-up)";
     case EncKernel::SingleU32: return "k_encode<false, true> (u32 tree)";
+    case EncKernel::Gen4: return "k_encode_gen<4> (4-bit symbols, lock-step, u32 tree in LDS)";
+    case EncKernel::Gen12: return "k_encode_gen<12> (12-bit symbols, lock-step, u32 tree in the workspace)";
     case EncKernel::Any: return "k_encode_any (general parameters, one lane per block)";
     }
     return "";
@@ -301,6 +327,8 @@ const char *redux_decode_kernel_name(const redux_params *p, const void *d_out, u
     case DecKernel::GenericU16: return "k_decode<true, false> (u16 tree, per-lane control flow)";
     case DecKernel::GenericU16Fixup: return "k_decode<true, true> (u16 tree, quotient fix-up)";
     case DecKernel::GenericU32: return "k_decode<false, true> (u32 tree)";
+    case DecKernel::Gen4: return "k_decode_gen<4> (4-bit symbols, lock-step, u32 tree in LDS)";
+    case DecKernel::Gen12: return "k_decode_gen<12> (12-bit symbols, lock-step, u32 tree in the workspace)";
     case DecKernel::Any: return "k_decode_any (general parameters, one lane per block)";
     }
     return "";
@@ -361,6 +389,34 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     uint8_t    *ws = (uint8_t *)d_workspace;
 
     HIP_TRY(hipMemsetAsync(ws + g.off_mode, 0, 256 + kClaimWords * 4, s)); // linear slots unless the pair kernel runs (below); empty role book
+    if (g.gen) {
+        GenEncArgs ga;
+        ga.in         = (const uint8_t *)d_in;
+        ga.in_len     = in_len;
+        ga.nblocks    = g.nblocks;
+        ga.slots      = ws + g.off_slots;
+        ga.slot_bytes = g.slot_bytes;
+        ga.sizes      = (uint32_t *)(ws + g.off_sizes);
+        ga.status     = (int32_t *)d_block_status;
+        ga.rc         = (const double *)(ws + g.off_rc);
+        ga.trees      = (uint32_t *)(ws + g.off_trees);
+        ga.block_size = block_size;
+        ga.slot_cap   = g.slot_cap;
+        ga.nfreeze    = g.nfreeze;
+        ga.code_bits  = p->code_bits;
+        if (64ull * g.slot_bytes >= (1ull << 32) || 64ull * block_size >= (1ull << 32)) // 64 slots / blocks within a 32-bit lane offset
+            return REDUX_UNSUPPORTED;
+        const uint32_t grid = (uint32_t)((g.nblocks + 63) / 64);
+        k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)(ws + g.off_rc), g.rc_n, (1u << p->symbol_bits) + 1u);
+        if (p->symbol_bits == 4)
+            k_encode_gen<4><<<grid, 64, 0, s>>>(ga);
+        else {
+            HIP_TRY(hipMemsetAsync(ws + g.off_trees, 0, (uint64_t)grid * GenTree<12>::kBytes, s)); // every tree starts at all-ones frequencies
+            k_encode_gen<12><<<grid, 64, 0, s>>>(ga);
+        }
+        HIP_TRY(hipGetLastError());
+        return REDUX_OK;
+    }
     if (g.any) {
         AnyEncArgs aa;
         aa.in         = (const uint8_t *)d_in;
@@ -412,6 +468,8 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     case EncKernel::SingleU16: k_encode<true, false><<<grid, 64, 0, s>>>(a); break;
     case EncKernel::SingleU16Fixup: k_encode<true, true><<<grid, 64, 0, s>>>(a); break;
     case EncKernel::SingleU32: k_encode<false, true><<<grid, 64, 0, s>>>(a); break;
+    case EncKernel::Gen4:
+    case EncKernel::Gen12:
     case EncKernel::Any: break; // handled above
     }
     HIP_TRY(hipGetLastError());
@@ -519,6 +577,8 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
     if (check_params(p) != REDUX_OK || block_size == 0)
         return 0;
     const Geometry g = geometry(p, block_size, block_size);
+    if (g.gen)
+        return align_up((uint64_t)g.rc_n * 8, 256) + ((nblocks ? nblocks : 1) + 63) / 64 * 64 * g.tree_bytes;
     if (g.any)
         return (nblocks ? nblocks : 1) * g.tree_bytes;
     return align_up((uint64_t)g.rc_n * 8, 256);
@@ -544,6 +604,33 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     if (workspace_bytes < redux_decode_workspace_bytes(p, nblocks, block_size))
         return REDUX_OUTPUT_TOO_SMALL;
     hipStream_t s = (hipStream_t)stream;
+    if (g.gen) {
+        GenDecArgs ga;
+        ga.in         = (const uint8_t *)d_in;
+        ga.in_offsets = (const uint64_t *)d_in_offsets;
+        ga.nblocks    = nblocks;
+        ga.out        = (uint8_t *)d_out;
+        ga.out_sizes  = (uint32_t *)d_out_sizes;
+        ga.status     = (int32_t *)d_block_status;
+        ga.rc         = (const double *)d_workspace;
+        ga.trees      = (uint32_t *)((uint8_t *)d_workspace + align_up((uint64_t)g.rc_n * 8, 256));
+        ga.in_used    = (uint64_t *)d_in_used;
+        ga.block_size = block_size;
+        ga.nfreeze    = g.nfreeze;
+        ga.code_bits  = p->code_bits;
+        const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
+        k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)d_workspace, g.rc_n, (1u << p->symbol_bits) + 1u);
+        if (p->symbol_bits == 4)
+            k_decode_gen<4><<<grid, 64, 0, s>>>(ga);
+        else {
+            HIP_TRY(hipMemsetAsync(ga.trees, 0, (uint64_t)grid * GenTree<12>::kBytes, s));
+            k_decode_gen<12><<<grid, 64, 0, s>>>(ga);
+        }
+        if (d_summary)
+            k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
+        HIP_TRY(hipGetLastError());
+        return REDUX_OK;
+    }
     if (g.any) {
         AnyDecArgs aa;
         aa.in         = (const uint8_t *)d_in;
@@ -586,6 +673,8 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     case DecKernel::GenericU16: k_decode<true, false><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::GenericU16Fixup: k_decode<true, true><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::GenericU32: k_decode<false, true><<<grid, 64, 0, s>>>(a); break;
+    case DecKernel::Gen4:
+    case DecKernel::Gen12:
     case DecKernel::Any: break; // handled above
     }
     if (d_summary)

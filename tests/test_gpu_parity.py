@@ -893,7 +893,10 @@ def test_kernel_names_follow_the_dispatch(rx):
     assert enc((8, 14, 16), 0, 1 << 30, 65536).startswith("k_encode_pair<false, false>")
     assert enc((8, 30, 32), 4, 1 << 30, 65536).startswith("k_encode<true, false>")     # unaligned input
     assert enc((8, 30, 32), 0, 1 << 30, 1 << 20).startswith("k_encode<false, true>")    # u32 tree
-    assert enc((12, 14, 16), 0, 1 << 20, 65536).startswith("k_encode_any")
+    assert enc((12, 14, 16), 0, 1 << 20, 65536).startswith("k_encode_gen<12>")
+    assert enc((4, 10, 16), 0, 1 << 20, 65536).startswith("k_encode_gen<4>")
+    assert enc((12, 20, 44), 0, 1 << 20, 65536).startswith("k_encode_any")              # code_bits > 32
+    assert enc((5, 10, 16), 0, 1 << 20, 65536).startswith("k_encode_any")
     assert dec((8, 30, 32), 65536).startswith("k_decode_lock<true>")
     assert dec((8, 22, 24), 65536).startswith("k_decode_lock<false>")
     assert dec((8, 30, 32), 1001, 2).startswith("k_decode_lock<true>")
@@ -965,3 +968,33 @@ def test_host_abi_from_two_threads_and_release(rx):
     assert _lib.lib().redux_host_release() == 0       # the context is rebuilt on the next call
     out, offs, st = rx.compress_blocks(text, BLOCK, (8, 30, 32))
     assert split(out, offs) == want
+
+
+@pytest.mark.parametrize("params", [(4, 10, 16), (4, 22, 24), (4, 28, 32), (12, 14, 16), (12, 18, 30), (12, 20, 32)])
+def test_lockstep_kernels_for_4_and_12_bit_symbols(rx, params):
+    """The widths src/model/tests.rs:95-251 exercises besides 8, on the lock-step kernels of redux_gen.hpp:
+    64 KiB blocks (131,072 resp. 43,690 symbols: the model freezes inside the block for the narrow frequency
+    widths, count passes 2^17 for 4-bit symbols), ragged tail, 70 blocks = two waves, streams bit-exact with the
+    oracle, decode equal to the oracle's decode (12-bit symbols: the trailing 8 bits of a 64 KiB block are dropped)."""
+    import ctypes as C
+    from redux_amd import _lib
+    p = _lib.Params(*params)
+    assert _lib.lib().redux_encode_kernel_name(C.byref(p), None, 1 << 20, BLOCK).decode().startswith(f"k_encode_gen<{params[0]}>")
+    assert _lib.lib().redux_decode_kernel_name(C.byref(p), None, BLOCK).decode().startswith(f"k_decode_gen<{params[0]}>")
+    rng = np.random.default_rng(params[0] * 100 + params[1])
+    text = open(os.path.join(GOLDEN, "corpora", "large", "world192.txt"), "rb").read()
+    data = (text + rng.integers(0, 256, 70 * BLOCK - len(text) + 4321, dtype=np.uint8).tobytes())
+    data = data[: 69 * BLOCK + 4321]
+    out, offs, st = rx.compress_blocks(data, BLOCK, params)
+    nb = len(offs) - 1
+    assert nb == 70 and not st.any()
+    dec, sizes, dst = rx.decompress_blocks(out, offs, BLOCK, params)
+    assert not dst.any()
+    for b in (0, 1, 36, 37, 63, 64, 68, 69):
+        blk = data[b * BLOCK:(b + 1) * BLOCK]
+        want, _ = ox.compress(blk, params)
+        assert out[int(offs[b]): int(offs[b + 1])].tobytes() == want, (params, b)
+        stw, outw = _oracle_decode_raw(want, BLOCK, params)
+        assert stw == 0 and dec[b * BLOCK: b * BLOCK + int(sizes[b])].tobytes() == outw, (params, b)
+        keep = len(blk) * 8 // params[0] * params[0] // 8   # whole symbols, whole bytes
+        assert outw == blk[:keep]
