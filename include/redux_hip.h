@@ -15,7 +15,8 @@
  *   - Status codes mirror src/lib.rs:57-64: 0 Ok, 1 Eof, 2 InvalidInput, 3 IoError (here: a
  *     HIP runtime failure), plus 4 OutputTooSmall and 5 Unsupported (parameters the device
  *     path does not implement: symbol_bits > 16; symbol_bits == 8 with code_bits <= 32 runs on
- *     the fast kernels, every other valid triple on a one-lane-per-block kernel).  There is NO
+ *     the fast kernels, 4- and 12-bit symbols with code_bits <= 32 on lock-step kernels of the
+ *     same form, every other valid triple on a one-lane-per-block kernel).  There is NO
  *     CPU fallback: Unsupported is returned, never silently served by other code.
  *   - The caller owns every buffer.  Host-pointer calls are synchronous.  `_dev` calls take
  *     device pointers, enqueue on `stream` (a hipStream_t passed as void*, NULL = default
