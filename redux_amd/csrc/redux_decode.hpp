@@ -271,6 +271,19 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
 #ifdef REDUX_DEC_CENSUS // diagnostic build: where each decode wave ran (tools/dec_census.py)
 __device__ uint32_t g_dec_hw[4096];
 #endif
+#ifdef REDUX_DEC_GSTAMPS // diagnostic build: two stamps per GROUP of four steps: [0] the group's preamble (retire the
+                         // stream chunk, store the output, request the next chunk), [1] its four steps
+__device__ uint64_t g_dec_ts[8];
+#define DEC_GSTAMP(i)                                                                                                  \
+    {                                                                                                                  \
+        uint64_t t_;                                                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                   \
+        gts[i] += t_ - gt0;                                                                                            \
+        gt0 = t_;                                                                                                      \
+    }
+#else
+#define DEC_GSTAMP(i)
+#endif
 #ifdef REDUX_DEC_STAMPS // diagnostic build: cycle stamps inside the lock-step step (tools/dec_stamps.sh)
 __device__ uint64_t g_dec_ts[8];
 #define DEC_STAMP(i, dep)                                                                                              \
@@ -741,6 +754,9 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
 #ifdef REDUX_DEC_STAMPS
     uint64_t dec_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dec_t0 = clock64();
 #endif
+#ifdef REDUX_DEC_GSTAMPS
+    uint64_t gts[2] = {0, 0}, gt0 = clock64();
+#endif
     if (aligned4) {
         double cdm1 = STATIC ? (double)(c_const - 1u) : 256.0, cd = STATIC ? (double)c_const : 257.0;
         // The group's four reciprocals are loaded a group ahead with VECTOR loads (every lane the
@@ -755,10 +771,12 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
         for (; p + 4 <= pfast; p += 4) {
             if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
                 break;
+            DEC_GSTAMP(1)
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
             REDUX_DEC_REQUEST
             rcn = STATIC ? rcg : rcv[(p >> 2) + 1]; // the table has 32 entries of slack (geometry())
+            DEC_GSTAMP(0)
 #pragma unroll
             for (int K = 0; K < 4; K++) {
                 const double   rc = rcg[K];
@@ -890,6 +908,13 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     if (blockIdx.x == 7 && lane == 0)
         for (int i = 0; i < 8; i++)
             g_dec_ts[i] = i < 7 ? dec_ts[i] : p;
+#endif
+#ifdef REDUX_DEC_GSTAMPS
+    if (blockIdx.x == 7 && lane == 0) {
+        g_dec_ts[0] = gts[0];
+        g_dec_ts[1] = gts[1];
+        g_dec_ts[7] = p;
+    }
 #endif
     // ---------------- remaining steps (EOF symbol, frozen model, unaligned output) ----------------
     for (;; p++) {

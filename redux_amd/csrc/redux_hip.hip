@@ -689,7 +689,7 @@ extern "C" int redux_debug_dec_census(uint32_t *out4096)
     return (int)hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_dec_hw), 4096 * 4);
 }
 #endif
-#ifdef REDUX_DEC_STAMPS
+#if defined(REDUX_DEC_STAMPS) || defined(REDUX_DEC_GSTAMPS)
 extern "C" int redux_debug_dec_stamps(uint64_t *out8)
 {
     return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dec_ts), 64);
