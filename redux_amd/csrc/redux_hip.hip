@@ -461,7 +461,7 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     // what the pair kernel leaves in the slots (CompactArgs::mode): byte 0x01 -> row-major group
     // areas, 0x02 -> linear slots whose dwords are byte-reversed
     if ((which == EncKernel::PairCb32 || which == EncKernel::Pair) && (REDUX_ROWS || REDUX_PAIR_SWAP))
-        HIP_TRY(hipMemsetAsync(ws + g.off_mode, REDUX_ROWS ? 1 : 2, 4, s));
+        HIP_TRY(hipMemsetAsync(ws + g.off_mode, (REDUX_ROWS ? 1 : 0) | (REDUX_PAIR_SWAP ? 2 : 0), 4, s));
     switch (which) {
     case EncKernel::PairCb32: k_encode_pair<false, true><<<grid, 128, 0, s>>>(a); break;
     case EncKernel::Pair: k_encode_pair<false, false><<<grid, 128, 0, s>>>(a); break;
@@ -513,7 +513,8 @@ static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *
 #if REDUX_ROWS // the mode word decides on the device which of the two does the work
     if (!g.any && g.u16) {
         const uint32_t tiles = (ca.cap_rows + kTileRows - 1) / kTileRows + 1;
-        k_compact_rows<<<(uint32_t)((g.nblocks + 63) / 64) * tiles, 256, 0, s>>>(ca);
+        const uint32_t groups = (uint32_t)((g.nblocks + 63) / 64);
+        k_compact_rows<<<(REDUX_ROWS_XCD ? (groups + 7) / 8 * 8 : groups) * tiles, 256, 0, s>>>(ca);
     }
 #endif
     HIP_TRY(hipGetLastError());

@@ -4,7 +4,7 @@
 //   k_scan_sizes     sizes -> offsets (exclusive scan, one workgroup) + status summary;
 //                    k_scan_sizes_coalesced for whole chunks of 4096 blocks (the headline shape)
 //   k_compact        slot b [0, size_b) -> out + offsets[b], 16-byte stores with byte realignment
-//   k_compact_rows   the same from row-major group areas (-DREDUX_ROWS=1 builds)
+//   k_compact_rows   the same from row-major group areas (what k_encode_pair leaves; -DREDUX_ROWS=0 builds: never)
 //
 // Included by redux_hip.hip (one translation unit).
 #pragma once
@@ -324,17 +324,34 @@ __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
 // at byte offset sh (0..3) inside its first aligned dword is the byte-funnel of source dwords
 // j-1 and j.  Only a stream's first and last output dword can be partial: those go bytewise.
 constexpr uint32_t kTileRows = 64;
+#ifndef REDUX_ROWS_XCD
+#define REDUX_ROWS_XCD 1
+#endif
 __global__ void __launch_bounds__(256) k_compact_rows(CompactArgs a)
 {
-    if ((*a.mode & 1u) == 0)
+    const uint32_t mode = *a.mode;
+    if ((mode & 1u) == 0)
         return;
+    const uint32_t sel = (mode & 2u) ? 0x00010203u : 0x03020100u; // v_perm selector that restores stream order (kSwapped)
     __shared__ uint32_t tile[(kTileRows + 1) * 65]; // +1 leading row (source dword j-1); pitch 65: conflict-free column reads
     __shared__ uint64_t s_dst[64];                  // aligned dword that holds each stream's first byte (0: skip the stream)
     __shared__ uint32_t s_n[64], s_sh[64];
     __shared__ uint32_t s_maxj;
     const uint32_t tiles = (a.cap_rows + kTileRows - 1) / kTileRows + 1;
+#if REDUX_ROWS_XCD
+    // XCD-aware mapping: workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  A
+    // stream's consecutive 256-byte runs come from consecutive tiles of its group and share cache lines at their
+    // ends: all tiles of a group go to ONE XCD (blockIdx = 8 * (8-group block * tiles + tile) + group's slot), so the
+    // partial lines merge in that L2 instead of leaving two L2s as two partial writes.
+    const uint32_t y   = blockIdx.x >> 3;
+    const uint64_t g   = (uint64_t)(y / tiles) * 8 + (blockIdx.x & 7u);
+    const uint32_t r0  = (y % tiles) * kTileRows;
+    if (g * 64 >= a.nblocks)
+        return;
+#else
     const uint64_t g     = blockIdx.x / tiles;
     const uint32_t r0    = (blockIdx.x % tiles) * kTileRows;
+#endif
     const uint32_t tid   = threadIdx.x;
     if (tid == 0)
         s_maxj = 0;
@@ -401,7 +418,7 @@ __global__ void __launch_bounds__(256) k_compact_rows(CompactArgs a)
         uint32_t src[5];
 #pragma unroll
         for (int c = 0; c < 5; c++)
-            src[c] = tile[(jq + c) * 65 + l]; // source dwords j0-1 .. j0+3
+            src[c] = __builtin_amdgcn_perm(0u, tile[(jq + c) * 65 + l], sel); // source dwords j0-1 .. j0+3, in stream order
         uint32_t w[4];
 #pragma unroll
         for (int c = 0; c < 4; c++)
