@@ -946,9 +946,10 @@ int redux_host_release(void) { return host::ctx_release_all(); }
 uint64_t redux_host_allocations(void)
 {
     uint64_t n = 0;
-    std::lock_guard<std::mutex> l(host::g_ctx_mu);
-    for (const host::Ctx &c : host::g_ctx)
+    for (host::Ctx &c : host::g_ctx) {
+        std::lock_guard<std::mutex> l(c.mu);
         n += c.allocs;
+    }
     return n;
 }
 

@@ -158,7 +158,6 @@ static double now_s()
 }
 
 static Ctx g_ctx[16];
-static std::mutex g_ctx_mu;
 
 #define HOST_TRY(expr)                                                                                 \
     do {                                                                                               \
@@ -198,31 +197,36 @@ static int grow_pinned(Ctx &c, Buf &b, size_t need)
     return REDUX_OK;
 }
 
-static int ctx_get(Ctx **out)
+// the context of HIP's current device; its streams, events and staging ring are created by the first call that
+// holds its mutex (ctx_init_locked) and torn down by redux_host_release under the same mutex
+static int ctx_of_current_device(Ctx **out)
 {
     int dev = 0;
     HOST_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16)
         return REDUX_UNSUPPORTED;
-    Ctx &c = g_ctx[dev];
-    std::lock_guard<std::mutex> l(g_ctx_mu);
-    if (!c.ready) {
-        c.device = dev;
-        int pri_lo = 0, pri_hi = 0; // numerically: lo = least urgent, hi = most urgent
-        HOST_TRY(hipDeviceGetStreamPriorityRange(&pri_lo, &pri_hi));
-        for (int i = 0; i < kStreams; i++)
-            HOST_TRY(hipStreamCreateWithPriority(&c.stream[i], hipStreamNonBlocking, (i & 1) ? pri_hi : pri_lo));
-        HOST_TRY(hipStreamCreateWithFlags(&c.drain, hipStreamNonBlocking));
-        for (int i = 0; i < kSlots; i++)
-            HOST_TRY(hipEventCreateWithFlags(&c.slot[i].done, hipEventDisableTiming));
-        for (int i = 0; i < kPieces; i++) {
-            HOST_TRY(hipHostMalloc(&c.piece[i], kPieceBytes, hipHostMallocDefault));
-            HOST_TRY(hipEventCreateWithFlags(&c.piece_free[i], hipEventDisableTiming));
-            c.allocs++;
-        }
-        c.ready = true;
+    g_ctx[dev].device = dev;
+    *out              = &g_ctx[dev];
+    return REDUX_OK;
+}
+
+static int ctx_init_locked(Ctx &c) // c.mu is held
+{
+    if (c.ready)
+        return REDUX_OK;
+    int pri_lo = 0, pri_hi = 0; // numerically: lo = least urgent, hi = most urgent
+    HOST_TRY(hipDeviceGetStreamPriorityRange(&pri_lo, &pri_hi));
+    for (int i = 0; i < kStreams; i++)
+        HOST_TRY(hipStreamCreateWithPriority(&c.stream[i], hipStreamNonBlocking, (i & 1) ? pri_hi : pri_lo));
+    HOST_TRY(hipStreamCreateWithFlags(&c.drain, hipStreamNonBlocking));
+    for (int i = 0; i < kSlots; i++)
+        HOST_TRY(hipEventCreateWithFlags(&c.slot[i].done, hipEventDisableTiming));
+    for (int i = 0; i < kPieces; i++) {
+        HOST_TRY(hipHostMalloc(&c.piece[i], kPieceBytes, hipHostMallocDefault));
+        HOST_TRY(hipEventCreateWithFlags(&c.piece_free[i], hipEventDisableTiming));
+        c.allocs++;
     }
-    *out = &c;
+    c.ready = true;
     return REDUX_OK;
 }
 
@@ -231,13 +235,19 @@ static void free_buf_pin(Buf &b) { if (b.p) (void)hipHostFree(b.p); b.p = nullpt
 
 static int ctx_release_all()
 {
-    std::lock_guard<std::mutex> l(g_ctx_mu);
+    int caller_dev = -1;
+    (void)hipGetDevice(&caller_dev); // restored below: freeing another device's context must not move the caller
+    struct Restore {
+        int d;
+        ~Restore() { if (d >= 0) (void)hipSetDevice(d); }
+    } restore{caller_dev};
     for (Ctx &c : g_ctx) {
+        std::lock_guard<std::mutex> lc(c.mu); // waits for a call in flight on that device
         if (!c.ready)
             continue;
-        std::lock_guard<std::mutex> lc(c.mu);
         (void)hipSetDevice(c.device);
-        (void)hipDeviceSynchronize();
+        for (int i = 0; i < kStreams; i++) // (a call in flight holds c.mu, so these are idle: belt and braces)
+            if (c.stream[i]) (void)hipStreamSynchronize(c.stream[i]);
         for (Slot &s : c.slot) {
             free_buf_dev(s.d_in); free_buf_dev(s.d_ws); free_buf_dev(s.d_out); free_buf_dev(s.d_off); free_buf_dev(s.d_sz);
             free_buf_dev(s.d_st); free_buf_dev(s.d_sum); free_buf_dev(s.d_used);
@@ -316,11 +326,13 @@ static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_l
                          uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
 {
     Ctx *cp = nullptr;
-    int  rc = ctx_get(&cp);
+    int  rc = ctx_of_current_device(&cp);
     if (rc != REDUX_OK)
         return rc;
     Ctx &c = *cp;
     std::lock_guard<std::mutex> lock(c.mu);
+    if ((rc = ctx_init_locked(c)) != REDUX_OK)
+        return rc;
 
     const uint64_t nblocks = redux_block_count(in_len, block_size);
     const uint64_t cb      = chunk_blocks_for(nblocks, block_size, kEncChunkMax);
@@ -456,11 +468,13 @@ static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_
                                                             void *))
 {
     Ctx *cp = nullptr;
-    int  rc = ctx_get(&cp);
+    int  rc = ctx_of_current_device(&cp);
     if (rc != REDUX_OK)
         return rc;
     Ctx &c = *cp;
     std::lock_guard<std::mutex> lock(c.mu);
+    if ((rc = ctx_init_locked(c)) != REDUX_OK)
+        return rc;
 
     const uint64_t cb      = chunk_blocks_for(nblocks, block_size, kDecChunkMax);
     const uint64_t nchunks = (nblocks + cb - 1) / cb;
