@@ -44,6 +44,7 @@ extern "C" {
                       out_cap: u64, bytes_in: *mut u64, bytes_out: *mut u64) -> c_int;
     fn redux_decompress(p: *const ReduxParams, input: *const u8, in_len: u64, out: *mut u8,
                         out_cap: u64, bytes_in: *mut u64, bytes_out: *mut u64) -> c_int;
+    fn redux_host_release() -> c_int;
 }
 
 /// Status codes of include/redux_hip.h -> `redux::Error` (src/lib.rs:57-64).
@@ -68,6 +69,15 @@ pub fn supports(p: &Parameters) -> bool {
     let cp = c_params(p);
     unsafe {
         redux_params_check(cp.symbol_bits, cp.freq_bits, cp.code_bits) == 0 && redux_device_supports(&cp) == 0
+    }
+}
+
+/// The library keeps one lazily built, mutex-guarded context per GPU for these calls (chunk slots in HBM, pinned
+/// staging, streams), grown on demand and reused: calls from several threads are safe and run one after the other.
+/// `release` frees it (it is rebuilt by the next call); a long-lived process that is done coding may call it.
+pub fn release() {
+    unsafe {
+        redux_host_release();
     }
 }
 
