@@ -266,6 +266,16 @@ def main():
         for b in (0, sample_blocks // 2, sample_blocks - 1):
             g = enc.out[int(offs[b]): int(offs[b + 1])].cpu().numpy()
             assert (g == o[b * slot: b * slot + int(sizes[b])]).all(), f"block {b} differs from the CPU oracle"
+        # the LITERAL drop-in (redux::compress of one whole stream = one GPU lane, host-pointer ABI), for scale: a
+        # serial adaptive stream has no GPU parallelism, the blocked API above is the accelerated path
+        import io
+        one = host[: 1 << 20].tobytes()
+        sink = io.BytesIO()
+        rx.compress(io.BytesIO(one[:4096]), io.BytesIO(), rx.AdaptiveTreeModel.new(rx.Parameters.new(*PARAMS)))
+        t1 = time.perf_counter()
+        rx.compress(io.BytesIO(one), sink, rx.AdaptiveTreeModel.new(rx.Parameters.new(*PARAMS)))
+        one_lane = len(one) / (time.perf_counter() - t1) / 1e6
+        assert sink.getvalue() == ox.compress(one, PARAMS)[0], "whole-stream drop-in differs from the CPU oracle"
         line["cpu_baseline"] = {
             "value": round(sample_blocks * BLOCK / dt / 1e6, 1),
             "unit": "MB/s",
@@ -274,6 +284,9 @@ def main():
             "sample": f"first {sample_blocks} blocks ({sample_blocks * BLOCK >> 20} MiB) of the same stream, C restatement "
                       f"of the reference (-O2), {cores} threads, one block per task; single thread: {single:.1f} MB/s; "
                       "sizes of all sampled blocks and bytes of 3 blocks compared with the GPU output",
+            "one_lane_drop_in_MBps": round(one_lane, 2),
+            "one_lane_note": "redux_compress (the literal redux::compress drop-in: the first 1 MiB as ONE stream on one GPU lane, "
+                             "PCIe included, bytes equal to the CPU oracle's): for scale against the single-thread figure above",
         }
     print(json.dumps(line))
     if world > 1:
