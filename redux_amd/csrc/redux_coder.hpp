@@ -51,6 +51,20 @@ typedef const __attribute__((address_space(4))) double *rc_ptr; // forces scalar
 //        symbol skipped.
 //   U32: d[] as u32, byte address = e*256 + 4*lane.  64 KiB per wave; any block length.
 // --------------------------------------------------------------------------------------
+// The masks finish() multiplies the node pairs with, one 16-byte row per value 0..256: (v * 0x8001 >> 2j) & 0x10001,
+// j = 0..3.  A byte s uses row s and row s + 1 (row 256 is all zero: the derived node 256 is added separately).
+// 4 KiB, read through the vector L1 by the pair kernel's model wave (REDUX_MASK_TABLE).
+struct MaskTable {
+    uint32_t v[257 * 4];
+    constexpr MaskTable() : v{}
+    {
+        for (uint32_t s = 0; s < 257; s++)
+            for (uint32_t j = 0; j < 4; j++)
+                v[4 * s + j] = ((s * 0x8001u) >> (2 * j)) & 0x10001u;
+    }
+};
+__device__ const MaskTable k_mask_table __attribute__((aligned(128))) = MaskTable();
+
 template <bool U16>
 struct Tree {
     static constexpr uint32_t kDwords = U16 ? 256 * 32 : 256 * 64;
@@ -187,6 +201,28 @@ struct Tree {
             lo = ls;
             hi = hs + (m >> 8) * d256;
         }
+    }
+    // finish() with the eight dot-product masks of (s, s+1) taken from k_mask_table instead of computed: they depend
+    // on the symbol alone, so the caller loads them symbols ahead through the vector memory path, which this kernel
+    // otherwise uses once per 16 symbols.  ms / mm = masks of s / of s+1.
+    __device__ __forceinline__ void finish_tab(uint32_t s, uint32_t d256, const Nodes &n, const uint4 &ms, const uint4 &mm,
+                                               uint32_t &lo, uint32_t &hi) const
+    {
+        static_assert(U16, "u16 trees only");
+        const uint32_t  m     = s + 1;
+        const uint32_t *xs    = n.x;
+        const uint32_t  a[4]  = {ms.x, ms.y, ms.z, ms.w};
+        const uint32_t  b[4]  = {mm.x, mm.y, mm.z, mm.w};
+        uint32_t        ls    = s;
+        uint32_t        hs    = __umul24(m >> 8, d256) + m;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(xs[2 * j + 1], xs[2 * j], sel));
+            ls = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, a[j]), ls, false);
+            hs = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, b[j]), hs, false);
+        }
+        lo = ls;
+        hi = hs;
     }
     template <bool UPD>
     __device__ __forceinline__ void get_frequency(uint32_t s, uint32_t d256, bool upd, uint32_t &lo,

@@ -349,12 +349,47 @@ constexpr int kPairStride = (REDUX_ROWS ? 256 : 4) | (REDUX_PAIR_SWAP ? kSwapped
 #ifndef REDUX_TOP_REG // 1: the model wave keeps node 128 (level 7) in a register while the model adapts
 #define REDUX_TOP_REG 1
 #endif
+// 1: the dot-product masks of finish() come from k_mask_table, loaded REDUX_MASK_AHEAD symbols ahead (14 VALU
+// instructions per symbol become two 16-byte loads); 0: computed, for A/B runs.
+#ifndef REDUX_MASK_TABLE
+#define REDUX_MASK_TABLE 1
+#endif
+#ifndef REDUX_MASK_AHEAD
+#define REDUX_MASK_AHEAD 8
+#endif
+#ifndef REDUX_CODER_TOUCH
+#define REDUX_CODER_TOUCH 1
+#endif
+static_assert(16 % REDUX_MASK_AHEAD == 0, "slot i % AHEAD must mean the same in every chunk");
+struct MaskPipe {
+    uint4 s[REDUX_MASK_AHEAD], m[REDUX_MASK_AHEAD];
+    __device__ __forceinline__ void load(int slot, uint32_t sym)
+    {
+        const char *e = reinterpret_cast<const char *>(k_mask_table.v) + (sym << 4);
+        s[slot]       = *reinterpret_cast<const uint4 *>(e);
+        m[slot]       = *reinterpret_cast<const uint4 *>(e + 16);
+#ifdef REDUX_PROBE_VMEM // experiment: N more 16-byte gathers per symbol, into accumulation registers nothing else uses
+        if (REDUX_PROBE_VMEM >= 1)
+            asm volatile("global_load_dwordx4 a[0:3], %0, %1" ::"v"((sym << 4) ^ 16u), "s"(k_mask_table.v) : "a0", "a1", "a2", "a3", "memory");
+        if (REDUX_PROBE_VMEM >= 2)
+            asm volatile("global_load_dwordx4 a[4:7], %0, %1" ::"v"((sym << 4) ^ 32u), "s"(k_mask_table.v) : "a4", "a5", "a6", "a7", "memory");
+#endif
+    }
+    // the first AHEAD symbols of a chunk (entering a run of model_chunk calls)
+    __device__ __forceinline__ void prime(const uint4 cur)
+    {
+#pragma unroll
+        for (int d = 0; d < REDUX_MASK_AHEAD; d++)
+            load(d, ((d < 4 ? cur.x : cur.y) >> (8 * (d & 3))) & 0xFFu);
+    }
+};
+
 template <bool UPD>
-__device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, uint32_t lane, const uint4 cur,
-                                            uint32_t p, uint32_t nfreeze, uint32_t *top = nullptr)
+__device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, uint32_t lane, const uint4 cur, const uint4 nxt,
+                                            MaskPipe &mp, uint32_t p, uint32_t nfreeze, uint32_t *top = nullptr)
 {
     constexpr int kInFlight = (UPD && REDUX_TOP_REG) ? 7 : 8; // LDS ops of one symbol
-    const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+    const uint32_t w[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
     auto sym = [&](int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; };
     // software pipeline: symbol i+1's LDS ops are in flight while symbol i's sums are formed
     // (depths 2 and 3 measured no faster: the pair is bound by the VALU instructions of both waves, not by LDS latency)
@@ -379,7 +414,12 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
         // compile time -- instead of the compiler's four, one in front of each v_perm, needs a
         // sched_barrier to stay in front of finish() and measures 1 % slower.)
         uint32_t lo, hi;
+#if REDUX_MASK_TABLE
+        T.finish_tab(s, nup, q[0], mp.s[i % REDUX_MASK_AHEAD], mp.m[i % REDUX_MASK_AHEAD], lo, hi);
+        mp.load(i % REDUX_MASK_AHEAD, sym(i + REDUX_MASK_AHEAD)); // (the last ones are the next chunk's)
+#else
         T.finish(s, nup, q[0], lo, hi);
+#endif
 #ifdef REDUX_PROBE_MODEL // experiment: N extra independent VALU instructions per symbol in the model wave
 #pragma unroll
         for (int k = 0; k < REDUX_PROBE_MODEL; k++) {
@@ -625,26 +665,35 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
             Q.init(wsrc, soff, main_end);
 #define NEXT_CHUNK() Q.pop()
 #else
-            uint4 cur = *reinterpret_cast<const uint4 *>(wsrc + soff);
-            auto  next_chunk = [&](uint32_t pp) {
-                const uint4 r = cur;
-                if (pp + 16 < main_end)
-                    cur = *reinterpret_cast<const uint4 *>(wsrc + soff + pp + 16);
+            uint4    held = *reinterpret_cast<const uint4 *>(wsrc + soff);
+            uint32_t held_at = 0;
+            auto  next_chunk = [&]() {
+                const uint4 r = held;
+                held_at += 16;
+                if (held_at < main_end)
+                    held = *reinterpret_cast<const uint4 *>(wsrc + soff + held_at);
                 return r;
             };
-#define NEXT_CHUNK() next_chunk(p)
+#define NEXT_CHUNK() next_chunk()
 #endif
+            // cur = the chunk at p, nxt the one after it (model_chunk loads masks a few symbols ahead, across the chunk boundary)
+            uint4    cur = NEXT_CHUNK(), nxt;
+            MaskPipe mp;
+            mp.prime(cur);
 #if REDUX_TOP_REG
             uint32_t top = 0; // node 128 in this lane's half, as the LDS dword would hold it
-            for (; p < a_end; p += 16)
-                model_chunk<true>(T, ring, lane, NEXT_CHUNK(), p, nfreeze, &top);
+            for (; p < a_end; p += 16, cur = nxt) {
+                nxt = NEXT_CHUNK(); // (one past the end at the last turn: the queue re-reads its last chunk)
+                model_chunk<true>(T, ring, lane, cur, nxt, mp, p, nfreeze, &top);
+            }
             T.add(T.A[7], top); // from here on (freeze-crossing chunk, frozen chunks, the coder wave's tail) the tree is read from LDS
 #else
-            for (; p < a_end; p += 16)
-                model_chunk<true>(T, ring, lane, NEXT_CHUNK(), p, nfreeze);
+            for (; p < a_end; p += 16, cur = nxt) {
+                nxt = NEXT_CHUNK();
+                model_chunk<true>(T, ring, lane, cur, nxt, mp, p, nfreeze);
+            }
 #endif
             for (; p < m_end; p += 16) { // rolled: the update stops in the middle of this chunk
-                (void)NEXT_CHUNK();
                 for (uint32_t i = 0; i < 16; i++) {
                     const uint32_t q   = p + i;
                     const uint32_t nup = q < nfreeze ? q : nfreeze;
@@ -654,9 +703,13 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
                     if ((i & 7) == 7)
                         pair_barrier();
                 }
+                cur = NEXT_CHUNK();
+                mp.prime(cur);
             }
-            for (; p < main_end; p += 16)
-                model_chunk<false>(T, ring, lane, NEXT_CHUNK(), p, nfreeze);
+            for (; p < main_end; p += 16, cur = nxt) {
+                nxt = NEXT_CHUNK();
+                model_chunk<false>(T, ring, lane, cur, nxt, mp, p, nfreeze);
+            }
 #undef NEXT_CHUNK
         }
     } else {
@@ -667,7 +720,18 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
         uint32_t p = 0;
         double   r[8];      // reciprocals of the first eight symbols of chunk r_at
         uint32_t r_at = ~0u;
+#if REDUX_CODER_TOUCH
+        uint32_t touched = 0; // destination of the touch loads: never read, live to the end so that nothing else is put there
+#endif
         for (; p < main_end; p += 16) {
+#if REDUX_CODER_TOUCH
+            // The model wave's vector loads return in order: a mask-table load issued behind an input-line load that
+            // misses to HBM is not usable before that line has arrived.  This wave has the slack (it waits ~60 cycles
+            // per symbol at the ring), so it pulls every input line into the L2 one line-time before the model wave
+            // asks for it: one 4-byte load per lane and 128 symbols, into a register nobody reads.
+            if ((p & 127u) == 0 && p + 256u + 4u <= main_end)
+                asm volatile("global_load_dword %0, %1, %2" : "+v"(touched) : "v"(soff + p + 256u), "s"(wsrc) : "memory");
+#endif
             if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit) || (p >= a_end && p < m_end))
                 coder_chunk_checked<FIXUP>(S, ring, lane, p, nfreeze, rc, sh, wdst, limit);
             else if (p < a_end) {
@@ -681,6 +745,9 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
             } else
                 coder_chunk<FIXUP, 1, CB32>(S, ring, lane, p, nfreeze, rc, sh, wdst, r);
         }
+#if REDUX_CODER_TOUCH
+        asm volatile("" ::"v"(touched));
+#endif
     }
     __syncthreads(); // the model wave's last updates are in LDS before the tail reads the tree
 #ifdef REDUX_STAMPS
