@@ -244,11 +244,21 @@ struct Tree {
 //   * FIXUP == true (c up to 2^30-1): the estimate is q or q+1; the remainder mod 2^32
 //     (in [0,c) or in [2^32-c, 2^32)) tells which.
 // f < c always (data symbols: h <= c-1; EOF low: c-1), so the quotient is < 2^32.
+//
+// NONZERO (the caller knows f >= 1: every high end of a range, cum(s + 1) >= s + 1): the floor is taken by an fma,
+// trunc(Y*f) = low dword of fma(Y, f, 2^52 - 0.5).  The exact sum lies in [2^52, 2^53) -- Y*f >= 2^13 here, the
+// interval is at least a quarter of the code space wide and c < 2^30 -- where one ulp is 1, so the fma's single
+// rounding is "Y*f - 0.5 to the nearest integer" = floor(Y*f) whenever Y*f is not an integer; and it never is: an
+// exact multiple x = n*c gives Y*f = n(1 + t) with 0 < n*t < 1, anything else lies strictly between floor(x/c) and
+// floor(x/c) + 1 by the bound above.  One instruction instead of v_mul_f64 + v_cvt_u32_f64, and the product is not
+// rounded before the floor.  (f = 0 is why the low end keeps the two-instruction form: 0 + 2^52 - 0.5 is exactly
+// representable one binade down, and its low dword is 0xFFFFFFFF.)  tests/test_fma_floor_cpu.py replays both forms
+// with exact rationals.
 // --------------------------------------------------------------------------------------
-template <bool FIXUP>
+template <bool FIXUP, bool NONZERO = false>
 __device__ __forceinline__ uint32_t scale_div(uint32_t R1, double Y, uint32_t f, uint32_t c)
 {
-    uint32_t q = (uint32_t)(Y * (double)f);
+    uint32_t q = NONZERO ? (uint32_t)__double_as_longlong(__builtin_fma(Y, (double)f, 0x1p52 - 0.5)) : (uint32_t)(Y * (double)f);
     if (FIXUP) {
         const uint32_t r = R1 * f + f - q * c;
         q -= (r >= c) ? 1u : 0u;
@@ -372,7 +382,7 @@ __device__ __forceinline__ uint32_t encode_symbol(EncState &S, uint32_t lo, uint
     const double   Y  = __builtin_fma((double)R1, rc, rc);
     const uint32_t nlow = S.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
     // EOF has hi == c: floor(range*c/c) = range, high is unchanged (and 2^32 would not fit).
-    const uint32_t nihigh = is_eof ? S.ihigh : ~(S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh) - 1u);
+    const uint32_t nihigh = is_eof ? S.ihigh : ~(S.low + (scale_div<FIXUP, true>(R1, Y, hi, c) << sh) - 1u);
 
     const uint32_t x    = ~(nlow ^ nihigh); // low ^ high
     const uint32_t k    = x ? (uint32_t)__builtin_clz(x) : 32u;
@@ -413,7 +423,7 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
     const uint32_t R1 = (~(S.ihigh + S.low)) >> sh;
     const double   Y  = __builtin_fma((double)R1, rc, rc);
     const uint32_t nlow   = S.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
-    uint32_t       nihigh = 0u - (S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh)); // ~(new high) = -(high + 1)
+    uint32_t       nihigh = 0u - (S.low + (scale_div<FIXUP, true>(R1, Y, hi, c) << sh)); // ~(new high) = -(high + 1)
     asm volatile("" : "+v"(nihigh)); // opaque: low ^ high is then one v_xnor, not (high+1)-1 followed by v_xor
 
     // k = clz(low ^ high), 32 for low == high (v_ffbh + v_min).  The 64-bit shifts then shift
@@ -497,7 +507,7 @@ __device__ __forceinline__ uint32_t encode_symbol_spec(EncState &S, SpecCarry &C
     const uint32_t R1 = C.r1 >> sh;
     const double   Y  = __builtin_fma((double)R1, rc, rc);
     const uint32_t nlow   = S.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
-    uint32_t       nihigh = 0u - (S.low + (scale_div<FIXUP>(R1, Y, hi, c) << sh));
+    uint32_t       nihigh = 0u - (S.low + (scale_div<FIXUP, true>(R1, Y, hi, c) << sh));
     const uint32_t x    = ~(nlow ^ nihigh);
     // 32-bit codes with count < 2^17 (!FIXUP): the interval is at least 2^30 wide before the
     // symbol and 2^30 / 2^17 after it, so low != high, x != 0 and k <= 31: no "x == 0 -> 32" select

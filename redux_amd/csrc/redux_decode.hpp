@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
             } else {
                 const double   Y     = __builtin_fma((double)R1, rc, rc);
                 const uint32_t nlow  = low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
-                const uint32_t nhigh = low + (scale_div<FIXUP>(R1, Y, hi, c) << sh) - 1u;
+                const uint32_t nhigh = low + (scale_div<FIXUP, true>(R1, Y, hi, c) << sh) - 1u;
                 const uint32_t xx    = nlow ^ nhigh;
                 const uint32_t k     = xx ? (uint32_t)__builtin_clz(xx) : 32u;
                 const uint32_t low2  = (uint32_t)((uint64_t)nlow << k);
@@ -512,7 +512,7 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
         dec_update(lds, A, T, f.s);
     const double   Y      = __builtin_fma(R1d, rc, rc);
     const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
-    const uint32_t nihigh = 0u - (S.low + (scale_div<false>(R1, Y, f.hi, c) << sh));
+    const uint32_t nihigh = 0u - (S.low + (scale_div<false, true>(R1, Y, f.hi, c) << sh));
     const uint32_t xx     = ~(nlow ^ nihigh);
     const uint32_t k      = xx ? (uint32_t)__builtin_clz(xx) : 32u;
     const uint32_t low2   = (uint32_t)((uint64_t)nlow << k);
@@ -824,7 +824,7 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                 uint32_t lo_ = f.lo;
                 {
                     const uint32_t a0 = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
-                    const uint32_t b0 = 0u - (S.low + (scale_div<false>(R1, Y, f.hi, c) << sh));
+                    const uint32_t b0 = 0u - (S.low + (scale_div<false, true>(R1, Y, f.hi, c) << sh));
                     const uint32_t x0 = ~(a0 ^ b0);
                     uint32_t       k0;
                     asm("v_ffbh_u32 %0, %1" : "=v"(k0) : "v"(x0));
@@ -836,7 +836,7 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
 #else
                 const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
 #endif
-                const uint32_t nihigh = 0u - (S.low + (scale_div<false>(R1, Y, f.hi, c) << sh));
+                const uint32_t nihigh = 0u - (S.low + (scale_div<false, true>(R1, Y, f.hi, c) << sh));
                 const uint32_t xx     = ~(nlow ^ nihigh);
                 uint32_t       k;
                 asm("v_ffbh_u32 %0, %1" : "=v"(k) : "v"(xx)); // -1 (sign bit) for low == high

@@ -391,6 +391,8 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
     constexpr int kInFlight = (UPD && REDUX_TOP_REG) ? 7 : 8; // LDS ops of one symbol
     const uint32_t w[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
     auto sym = [&](int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; };
+    // (Keeping the symbols the mask loads extracted, 8 registers, instead of extracting them again here: one VALU
+    // instruction fewer per symbol and 0.9 % slower, profiles/r02_masktable/ab.txt.)
     // software pipeline: symbol i+1's LDS ops are in flight while symbol i's sums are formed
     // (depths 2 and 3 measured no faster: the pair is bound by the VALU instructions of both waves, not by LDS latency)
     constexpr int D = REDUX_MODEL_DEPTH;

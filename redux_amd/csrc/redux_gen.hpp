@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(64) k_decode_gen(GenDecArgs a)
             } else {
                 const double   Y     = __builtin_fma((double)R1, rc, rc);
                 const uint32_t nlow  = low + (scale_div<true>(R1, Y, lo, c) << sh);
-                const uint32_t nhigh = low + (scale_div<true>(R1, Y, hi, c) << sh) - 1u;
+                const uint32_t nhigh = low + (scale_div<true, true>(R1, Y, hi, c) << sh) - 1u;
                 const uint32_t xx    = nlow ^ nhigh;
                 const uint32_t k     = xx ? (uint32_t)__builtin_clz(xx) : 32u;
                 const uint32_t low2  = (uint32_t)((uint64_t)nlow << k);
