@@ -218,8 +218,9 @@ struct Tree {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const u16x2 pv = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(xs[2 * j + 1], xs[2 * j], sel));
-            ls = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, a[j]), ls, false);
+            // (the masks of s + 1 were loaded second: used first, ONE vmcnt wait covers both loads)
             hs = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, b[j]), hs, false);
+            ls = __builtin_amdgcn_udot2(pv, __builtin_bit_cast(u16x2, a[j]), ls, false);
         }
         lo = ls;
         hi = hs;

@@ -357,6 +357,9 @@ constexpr int kPairStride = (REDUX_ROWS ? 256 : 4) | (REDUX_PAIR_SWAP ? kSwapped
 #ifndef REDUX_MASK_AHEAD
 #define REDUX_MASK_AHEAD 8
 #endif
+#ifndef REDUX_ONE_WAIT
+#define REDUX_ONE_WAIT 1
+#endif
 #ifndef REDUX_CODER_TOUCH
 #define REDUX_CODER_TOUCH 1
 #endif
@@ -412,10 +415,18 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
             q[D] = T.template issue<UPD>(sym(i + D), true, top);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // (One hand-placed s_waitcnt per symbol -- everything behind symbol i's node values is known at
-        // compile time -- instead of the compiler's four, one in front of each v_perm, needs a
-        // sched_barrier to stay in front of finish() and measures 1 % slower.)
+        // One hand-placed s_waitcnt for all seven node values of symbol i -- the ring write of i - 1 and the seven
+        // atomics of i + 1 are younger, so lgkmcnt(8) -- instead of the compiler's four, one in front of each
+        // v_perm: with the masks no longer computed the model wave is the pair's critical path and every issue slot
+        // of it counts (10.78 -> 10.61 ms; with a sched_barrier behind the wait 10.67; when the masks were still
+        // computed the same change measured 1 % slower).  The wait is a real S_WAITCNT, so the compiler's pass sees
+        // it and drops its own; where the count is different (chunk start, around the mid-chunk barrier) it is left
+        // to the compiler.  finish_tab() uses the masks loaded second first, so one vmcnt wait covers both loads.
         uint32_t lo, hi;
+#if REDUX_ONE_WAIT
+        if (D == 1 && i + D < 16 && !late && i != 8 && i != 0 && REDUX_MASK_TABLE && kInFlight == 7)
+            __builtin_amdgcn_s_waitcnt(0xC00F | 0x70 | (8 << 8)); // vmcnt and expcnt fields all ones = no wait
+#endif
 #if REDUX_MASK_TABLE
         T.finish_tab(s, nup, q[0], mp.s[i % REDUX_MASK_AHEAD], mp.m[i % REDUX_MASK_AHEAD], lo, hi);
         mp.load(i % REDUX_MASK_AHEAD, sym(i + REDUX_MASK_AHEAD)); // (the last ones are the next chunk's)
