@@ -360,8 +360,24 @@ constexpr int kPairStride = (REDUX_ROWS ? 256 : 4) | (REDUX_PAIR_SWAP ? kSwapped
 #ifndef REDUX_ONE_WAIT
 #define REDUX_ONE_WAIT 1
 #endif
+// 1: the ring holds the (low, high) pairs of two consecutive symbols side by side (16 bytes per lane), written by one
+// ds_write_b128 per two symbols and read by one ds_read_b128; 0: one 8-byte entry per symbol.
+#ifndef REDUX_RING_PAIRS
+#define REDUX_RING_PAIRS 1
+#endif
+__device__ __forceinline__ uint32_t ring_at(uint32_t i, uint32_t lane) // index of symbol i's entry, in uint2 units
+{
+    return REDUX_RING_PAIRS ? (i >> 1) * 128u + lane * 2u + (i & 1u) : i * 64u + lane;
+}
+// 1: the coder wave (which has the slack) pulls every input line into the L2 a line-time before the model wave asks for
+// it, so that the model wave's in-order vector loads are never queued behind an HBM miss: 1.3 % faster (10.57 -> 10.44
+// ms), but the lines do not stay in the L2 until they are used and FETCH_SIZE doubles (2.11e6 -> 4.18e6 KiB per 4 GiB;
+// 3.62e6 with the touch half a line later).  Not the default: the read side stays at 1.00 x the input.
 #ifndef REDUX_CODER_TOUCH
-#define REDUX_CODER_TOUCH 1
+#define REDUX_CODER_TOUCH 0
+#endif
+#ifndef REDUX_TOUCH_AT // where in its 128-symbol line the coder wave touches the line after next (a multiple of 16)
+#define REDUX_TOUCH_AT 0
 #endif
 static_assert(16 % REDUX_MASK_AHEAD == 0, "slot i % AHEAD must mean the same in every chunk");
 struct MaskPipe {
@@ -400,6 +416,7 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
     // (depths 2 and 3 measured no faster: the pair is bound by the VALU instructions of both waves, not by LDS latency)
     constexpr int D = REDUX_MODEL_DEPTH;
     Tree<true>::Nodes q[D + 1];
+    uint2             held = make_uint2(0, 0); // REDUX_RING_PAIRS: the even symbol of a pair, until the odd one is done
 #pragma unroll
     for (int d = 0; d < D; d++)
         q[d] = T.template issue<UPD>(sym(d), true, top);
@@ -425,7 +442,12 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
         uint32_t lo, hi;
 #if REDUX_ONE_WAIT
         if (D == 1 && i + D < 16 && !late && i != 8 && i != 0 && REDUX_MASK_TABLE && kInFlight == 7)
-            __builtin_amdgcn_s_waitcnt(0xC00F | 0x70 | (8 << 8)); // vmcnt and expcnt fields all ones = no wait
+        {
+            if (REDUX_RING_PAIRS && (i & 1)) // (no ring write between the atomics of i and of i + 1)
+                __builtin_amdgcn_s_waitcnt(0xC00F | 0x70 | (7 << 8));
+            else
+                __builtin_amdgcn_s_waitcnt(0xC00F | 0x70 | (8 << 8)); // vmcnt and expcnt fields all ones = no wait
+        }
 #endif
 #if REDUX_MASK_TABLE
         T.finish_tab(s, nup, q[0], mp.s[i % REDUX_MASK_AHEAD], mp.m[i % REDUX_MASK_AHEAD], lo, hi);
@@ -441,10 +463,17 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
         }
 #endif
         // (lo and hi come out of v_dot2, and gfx950 wants three wait states between a dot result and an
-        // LDS instruction reading it: the compiler puts an s_nop 2 here.  Pinning the next symbol's
-        // address preparation into that gap removes the s_nop and changes nothing: the kernel is
-        // bound by the VALU instructions of both waves together, not by the wave's issue slots.)
+        // LDS instruction reading it: the compiler puts an s_nop here.  Filling the gap instead -- the next symbol's
+        // address preparation pinned there in round 1, the two mask loads ordered there with sched_group_barrier
+        // in round 2 -- removes the s_nop and is no faster (10.64 against 10.53 ms for the latter).)
+#if REDUX_RING_PAIRS
+        if (i & 1) {
+            *reinterpret_cast<uint4 *>(ring + ring_at(i - 1, lane)) = make_uint4(held.x, held.y, lo, hi);
+        } else
+            held = make_uint2(lo, hi);
+#else
         ring[i * 64 + lane] = make_uint2(lo, hi);
+#endif
         if (late) {
             __builtin_amdgcn_sched_barrier(0);
             q[D] = T.template issue<UPD>(sym(i + D), true, top);
@@ -475,9 +504,18 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
     for (int h = 0; h < 2; h++) {
         pair_barrier();
         uint2 lh[8]; // the whole half at once: one LDS round trip per 8 symbols
+#if REDUX_RING_PAIRS
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const uint4 two = *reinterpret_cast<const uint4 *>(ring + ring_at(h * 8 + i, lane));
+            lh[i]     = make_uint2(two.x, two.y);
+            lh[i + 1] = make_uint2(two.z, two.w);
+        }
+#else
 #pragma unroll
         for (int i = 0; i < 8; i++)
             lh[i] = ring[(h * 8 + i) * 64 + lane];
+#endif
         double rn[8];
         if (MODE == 0) {
             uint32_t zero; // opaque 0 that "depends" on the ring data: pins the loads behind the LDS wait
@@ -548,7 +586,7 @@ __device__ __forceinline__ void coder_chunk_checked(EncState &S, const uint2 *ri
     for (uint32_t i = 0; i < 16; i++) {
         if ((i & 7) == 0)
             pair_barrier();
-        const uint2    lh  = ring[i * 64 + lane];
+        const uint2    lh  = ring[ring_at(i, lane)];
         const uint32_t q   = p + i;
         const uint32_t nup = q < nfreeze ? q : nfreeze;
         encode_symbol<FIXUP, kPairStride>(S, lh.x, lh.y, 257u + nup, rc[nup], sh, false, wdst, limit);
@@ -712,7 +750,7 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
                     const uint32_t nup = q < nfreeze ? q : nfreeze;
                     uint32_t       lo, hi;
                     T.template get_frequency<true>(wsrc[soff + q], nup, q < nfreeze, lo, hi);
-                    ring[i * 64 + lane] = make_uint2(lo, hi);
+                    ring[ring_at(i, lane)] = make_uint2(lo, hi);
                     if ((i & 7) == 7)
                         pair_barrier();
                 }
@@ -742,8 +780,8 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
             // misses to HBM is not usable before that line has arrived.  This wave has the slack (it waits ~60 cycles
             // per symbol at the ring), so it pulls every input line into the L2 one line-time before the model wave
             // asks for it: one 4-byte load per lane and 128 symbols, into a register nobody reads.
-            if ((p & 127u) == 0 && p + 256u + 4u <= main_end)
-                asm volatile("global_load_dword %0, %1, %2" : "+v"(touched) : "v"(soff + p + 256u), "s"(wsrc) : "memory");
+            if ((p & 127u) == REDUX_TOUCH_AT && (p & ~127u) + 256u + 4u <= main_end)
+                asm volatile("global_load_dword %0, %1, %2" : "+v"(touched) : "v"(soff + (p & ~127u) + 256u), "s"(wsrc) : "memory");
 #endif
             if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit) || (p >= a_end && p < m_end))
                 coder_chunk_checked<FIXUP>(S, ring, lane, p, nfreeze, rc, sh, wdst, limit);
