@@ -17,6 +17,11 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursi
 for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if sub in r["Kernel_Name"]]
     if d:
+        med = sorted(d)[len(d) // 2]
+        small = [x for x in d if x < med / 2]  # bench.py's cpu_baseline leg launches the kernel once on a 256 MiB sample
+        d = [x for x in d if x >= med / 2]
+        if small:
+            print("   (%d launch(es) on a smaller input left out of the means: %s ms)" % (len(small), " ".join("%.2f" % x for x in small)))
         k = min(10, len(d))
         print("== %s: %d launches matching %s, ms each: %s" % (os.path.relpath(f, root), len(d), sub, " ".join("%.2f" % x for x in d)))
         print("   mean of all %.3f ms; mean of the last %d (the timed steps of the default bench) %.3f ms" % (sum(d) / len(d), k, sum(d[-k:]) / k))

@@ -7,7 +7,7 @@ timeout -k 10 300 python bench.py --steps 10 --warmup 10 > $OUT/bench_iid.log 2>
 timeout -k 10 300 python bench.py --steps 10 --warmup 10 --workload zipf --no-cpu-baseline > $OUT/bench_zipf.log 2>&1 && tail -1 $OUT/bench_zipf.log
 timeout -k 10 300 python tools/measure_extra.py > $OUT/extra.log 2>&1 && tail -1 $OUT/extra.log
 timeout -k 10 600 bash tools/prof.sh $TAG > $OUT/prof.log 2>&1
-python3 tools/pmc_summary.py gpurun_out/prof_$TAG > $OUT/prof_summary.txt 2>&1
+python3 tools/pmc_summary.py gpurun_out/prof_$TAG k_encode_pair > $OUT/prof_summary.txt 2>&1
 timeout -k 10 400 bash tools/prof_decode.sh dec_$TAG > $OUT/prof_decode.txt 2>&1
 WORKLOAD=zipf timeout -k 10 400 bash tools/prof_traffic.sh zipf_$TAG > $OUT/prof_traffic_zipf.txt 2>&1
 cp $(ls -t gpurun_out/prof_$TAG/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
