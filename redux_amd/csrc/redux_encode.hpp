@@ -379,14 +379,44 @@ __device__ __forceinline__ uint32_t ring_at(uint32_t i, uint32_t lane) // index 
 #ifndef REDUX_TOUCH_AT // where in its 128-symbol line the coder wave touches the line after next (a multiple of 16)
 #define REDUX_TOUCH_AT 0
 #endif
+#ifndef REDUX_MASK_SDWA
+#define REDUX_MASK_SDWA 1
+#endif
+static_assert(REDUX_MASK_AHEAD == 4 || REDUX_MASK_AHEAD == 8, "prime() covers these");
 static_assert(16 % REDUX_MASK_AHEAD == 0, "slot i % AHEAD must mean the same in every chunk");
 struct MaskPipe {
-    uint4 s[REDUX_MASK_AHEAD], m[REDUX_MASK_AHEAD];
-    __device__ __forceinline__ void load(int slot, uint32_t sym)
+    uint4    s[REDUX_MASK_AHEAD], m[REDUX_MASK_AHEAD];
+    uint32_t four; // the constant 4 in a VGPR: SDWA has no inline constants on gfx9
+    __device__ __forceinline__ void init()
     {
-        const char *e = reinterpret_cast<const char *>(k_mask_table.v) + (sym << 4);
+        four = 4;
+        asm volatile("" : "+v"(four));
+    }
+    // byte K of w, times 16 = the row's offset: one SDWA shift (the byte select is part of the operand) instead of
+    // extract + shift -- the model wave's instruction count is what the kernel follows (section 4.0)
+    __device__ __forceinline__ uint32_t row_of(int K, uint32_t w) const // K: a constant once the caller's loop is unrolled
+    {
+        uint32_t off;
+#if REDUX_MASK_SDWA
+        if (K == 0)
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(four), "v"(w));
+        else if (K == 1)
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(four), "v"(w));
+        else if (K == 2)
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(four), "v"(w));
+        else
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(four), "v"(w));
+#else
+        off = ((w >> (8 * K)) & 0xFFu) << 4;
+#endif
+        return off;
+    }
+    __device__ __forceinline__ void load(int slot, uint32_t row) // row = 16 * symbol
+    {
+        const char *e = reinterpret_cast<const char *>(k_mask_table.v) + row;
         s[slot]       = *reinterpret_cast<const uint4 *>(e);
         m[slot]       = *reinterpret_cast<const uint4 *>(e + 16);
+        const uint32_t sym = row >> 4; // (only the probe below uses it)
 #ifdef REDUX_PROBE_VMEM // experiment: N more 16-byte gathers per symbol, into accumulation registers nothing else uses
         if (REDUX_PROBE_VMEM >= 1)
             asm volatile("global_load_dwordx4 a[0:3], %0, %1" ::"v"((sym << 4) ^ 16u), "s"(k_mask_table.v) : "a0", "a1", "a2", "a3", "memory");
@@ -397,9 +427,13 @@ struct MaskPipe {
     // the first AHEAD symbols of a chunk (entering a run of model_chunk calls)
     __device__ __forceinline__ void prime(const uint4 cur)
     {
-#pragma unroll
-        for (int d = 0; d < REDUX_MASK_AHEAD; d++)
-            load(d, ((d < 4 ? cur.x : cur.y) >> (8 * (d & 3))) & 0xFFu);
+        init();
+        const uint32_t w[2] = {cur.x, cur.y};
+        load(0, row_of(0, w[0])); load(1, row_of(1, w[0])); load(2, row_of(2, w[0])); load(3, row_of(3, w[0]));
+        if (REDUX_MASK_AHEAD == 8) {
+            load(4 % REDUX_MASK_AHEAD, row_of(0, w[1])); load(5 % REDUX_MASK_AHEAD, row_of(1, w[1]));
+            load(6 % REDUX_MASK_AHEAD, row_of(2, w[1])); load(7 % REDUX_MASK_AHEAD, row_of(3, w[1]));
+        }
     }
 };
 
@@ -451,7 +485,7 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
 #endif
 #if REDUX_MASK_TABLE
         T.finish_tab(s, nup, q[0], mp.s[i % REDUX_MASK_AHEAD], mp.m[i % REDUX_MASK_AHEAD], lo, hi);
-        mp.load(i % REDUX_MASK_AHEAD, sym(i + REDUX_MASK_AHEAD)); // (the last ones are the next chunk's)
+        mp.load(i % REDUX_MASK_AHEAD, mp.row_of((i + REDUX_MASK_AHEAD) & 3, w[(i + REDUX_MASK_AHEAD) >> 2])); // (the last ones are the next chunk's)
 #else
         T.finish(s, nup, q[0], lo, hi);
 #endif
