@@ -553,7 +553,11 @@ __device__ __forceinline__ uint32_t encode_symbol_spec(EncState &S, SpecCarry &C
     const uint32_t nb = C.nbm + m;
     if ((int32_t)nb >= 0) { // one exec-masked region: shift, byte swap, store, advance
 #ifndef REDUX_STORE_X4
+#ifdef REDUX_NO_STORE // timing experiment only (output invalid): what the stream stores cost
+        asm volatile("" ::"v"(stream_dword<ST>((uint32_t)(S.acc >> (nb & 63u)))), "v"(S.off));
+#else
         *reinterpret_cast<uint32_t *>(wbase + S.off) = stream_dword<ST>((uint32_t)(S.acc >> (nb & 63u)));
+#endif
         // in place: as plain C++ the sum lands in a new register and a v_mov merges it after the region
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(S.off) : "i"(stride_of<ST>) : "memory");
 #else
