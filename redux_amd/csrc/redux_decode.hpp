@@ -413,6 +413,20 @@ __device__ __forceinline__ DecFound dec_search_static(const uint32_t *tab, const
     return f;
 }
 
+// get_symbol under a static model whose total is at most 2^16, by direct lookup: lut[v] = the symbol whose range holds
+// v (one byte per code value, 64 KiB of LDS shared by the four waves of a workgroup), then cum[s] and cum[s+1] from the
+// plain table with one ds_read2_b32.  Two LDS round trips and six instructions where the descent above takes three
+// round trips and some fifty.
+__device__ __forceinline__ DecFound dec_search_lut(const uint8_t *lut, const uint32_t *ctab, uint32_t v, uint32_t cum256)
+{
+    DecFound f;
+    f.eofq = cum256 - 1u - v; // top bit set: v >= cum[256], the EOF symbol (lut[] holds 255 there)
+    f.s    = lut[v & 0xFFFFu]; // (a finished lane's v is garbage: stay inside the table)
+    f.lo   = ctab[f.s];
+    f.hi   = ctab[f.s + 1u];
+    return f;
+}
+
 // update(s+1) (adaptive_tree.rs:83-92): +1 on the levels where bit b of s is clear.  Levels 7-5
 // live in registers: node e of level b is incremented iff s lies in [e - 2^b, e), an unsigned
 // range compare + add-with-carry; levels 4-0 are fire-and-forget ds_add_u32.
@@ -558,15 +572,21 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
 // by the lanes) instead of 64 per-lane trees, nothing is updated, total frequency and reciprocal are constants.
 // Everything else -- code value, narrowing, renormalisation, bit reader, output staging, the careful per-lane
 // commit -- is the same code.
-template <bool CB32, bool STATIC>
-__device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds, const uint32_t *cum, double rc_static)
+// MODE 0: adaptive model; 1: static model, descent over the table's Fenwick form; 2: static model, direct lookup
+// (`lds` is then this wave's stream ring alone, `lut` / `ctab` the workgroup's shared tables, filled by the caller).
+template <bool CB32, int MODE>
+__device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds, const uint32_t *cum, double rc_static,
+                                                 uint32_t lane = threadIdx.x, uint64_t group = blockIdx.x,
+                                                 const uint8_t *lut = nullptr, const uint32_t *ctab = nullptr)
 {
-    constexpr uint32_t kModelBytes = STATIC ? kStaticTreeDwords * 4 : 128 * 64 * 4;
-    const uint32_t lane = threadIdx.x;
-    const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
+    constexpr bool     STATIC      = MODE != 0;
+    constexpr uint32_t kModelBytes = MODE == 2 ? 0 : MODE == 1 ? kStaticTreeDwords * 4 : 128 * 64 * 4;
+    const uint64_t blk  = group * 64 + lane;
     const bool     live = blk < a.nblocks;
 
-    if (STATIC) {
+    if (MODE == 2) {
+        // (tables filled by the caller, which also synchronises)
+    } else if (STATIC) {
         for (uint32_t i = lane; i < 256; i += 64)
             lds[dec_static_slot(i)] = i ? cum[i] - cum[i - (i & (0u - i))] : 0u;
     } else {
@@ -669,15 +689,15 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     uint4    oq     = make_uint4(0, 0, 0, 0);
     uint32_t p      = 0;
     DecTop   T      = dec_top_new();
-    if (STATIC)
+    if (MODE == 1)
         T = DecTop{lds[dec_static_slot(128)], lds[dec_static_slot(64)], lds[dec_static_slot(192)], lds[dec_static_slot(32)],
                    lds[dec_static_slot(96)], lds[dec_static_slot(160)], lds[dec_static_slot(224)]};
     const uint32_t cum256  = STATIC ? cum[256] : 0u;
     const uint32_t c_const = STATIC ? cum[257] : 0u; // total_frequency() of the static model
 #ifdef REDUX_DEC_STAMPS
-#define REDUX_DEC_SEARCH(v_, c_) (STATIC ? dec_search_static(lds, T, v_, cum256) : dec_search(lds, L, T, v_, c_, dec_ts, dec_t0))
+#define REDUX_DEC_SEARCH(v_, c_) (MODE == 2 ? dec_search_lut(lut, ctab, v_, cum256) : MODE == 1 ? dec_search_static(lds, T, v_, cum256) : dec_search(lds, L, T, v_, c_, dec_ts, dec_t0))
 #else
-#define REDUX_DEC_SEARCH(v_, c_) (STATIC ? dec_search_static(lds, T, v_, cum256) : dec_search(lds, L, T, v_, c_))
+#define REDUX_DEC_SEARCH(v_, c_) (MODE == 2 ? dec_search_lut(lut, ctab, v_, cum256) : MODE == 1 ? dec_search_static(lds, T, v_, cum256) : dec_search(lds, L, T, v_, c_))
 #endif
 
 #define REDUX_DEC_READER                                                                                               \
@@ -967,7 +987,7 @@ template <bool CB32>
 __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
 {
     __shared__ uint32_t lds[128 * 64 + 32 * 64]; // tree (32 KiB) + stream ring (8 KiB): four groups fill the CU's 160 KiB
-    decode_lock_body<CB32, false>(a, lds, nullptr, 0.0);
+    decode_lock_body<CB32, 0>(a, lds, nullptr, 0.0);
 }
 
 } // namespace redux

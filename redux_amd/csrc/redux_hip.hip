@@ -923,7 +923,19 @@ int redux_static_decode_blocks_dev(const redux_params *p, const uint32_t *cum, c
         la.rc           = a.rc;
         la.tab          = a.tab;
         const bool solo = grid <= 4u * cu_count(); // at most one wave per SIMD: keep the dispatcher from doubling them up
-        if (p->code_bits == 32) {
+        if (REDUX_STATIC_LUT && cum[kStaticEntries - 1] <= 65536u) { // get_symbol by direct lookup
+            if (solo) {
+                if (p->code_bits == 32)
+                    k_decode_static_lut<true, 4><<<(grid + 3) / 4, 256, 0, s>>>(la);
+                else
+                    k_decode_static_lut<false, 4><<<(grid + 3) / 4, 256, 0, s>>>(la);
+            } else {
+                if (p->code_bits == 32)
+                    k_decode_static_lut<true, 8><<<(grid + 7) / 8, 512, 0, s>>>(la);
+                else
+                    k_decode_static_lut<false, 8><<<(grid + 7) / 8, 512, 0, s>>>(la);
+            }
+        } else if (p->code_bits == 32) {
             if (solo)
                 k_decode_static_lock<true, true><<<grid, 64, 0, s>>>(la);
             else

@@ -313,7 +313,34 @@ __global__ void __launch_bounds__(64) k_decode_static_lock(StaticLockArgs a)
 {
     __shared__ uint32_t lds[kStaticTreeDwords + 32 * 64]; // Fenwick form of the table (~1 KiB, padded) + stream ring (8 KiB)
     claim_the_simd<SOLO>();
-    decode_lock_body<CB32, true>(a.d, lds, a.tab.cum, a.rc);
+    decode_lock_body<CB32, 1>(a.d, lds, a.tab.cum, a.rc);
+}
+
+#ifndef REDUX_STATIC_LUT // 0: the Fenwick descent (k_decode_static_lock) for every total below 2^17, for A/B runs
+#define REDUX_STATIC_LUT 1
+#endif
+// Totals up to 2^16: get_symbol by direct lookup (dec_search_lut).  WAVES waves share one 64 KiB byte table lut[v] =
+// symbol and the plain cumulative table; each has its own 8 KiB stream ring: 4 waves = 97 KiB, one workgroup and one wave
+// per SIMD on a CU (the headline shape: 1024 groups of 64 blocks), 8 waves = 129 KiB for grids beyond that.
+template <bool CB32, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_decode_static_lut(StaticLockArgs a)
+{
+    constexpr uint32_t kLutDwords = 65536 / 4, kTabDwords = 260;
+    __shared__ uint32_t lds[kLutDwords + kTabDwords + WAVES * 32 * 64];
+    uint8_t  *lut  = reinterpret_cast<uint8_t *>(lds);
+    uint32_t *ctab = lds + kLutDwords;
+    const uint32_t t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    for (uint32_t i = t; i < kStaticEntries; i += 64 * WAVES)
+        ctab[i] = a.tab.cum[i];
+    // symbol s fills [cum[s], cum[s+1]); the EOF symbol's range (and nothing beyond the total is ever looked up) gets 255
+    for (uint32_t s = t; s < 257; s += 64 * WAVES) {
+        const uint32_t b = a.tab.cum[s], e = a.tab.cum[s + 1] < 65536u ? a.tab.cum[s + 1] : 65536u;
+        for (uint32_t i = b; i < e; i++)
+            lut[i] = (uint8_t)(s < 256 ? s : 255);
+    }
+    __syncthreads();
+    decode_lock_body<CB32, 2>(a.d, ctab + kTabDwords + wave * (32 * 64), a.tab.cum, a.rc, t & 63u,
+                              (uint64_t)blockIdx.x * WAVES + wave, lut, ctab);
 }
 
 } // namespace redux

@@ -396,7 +396,7 @@ def _static_tables():
     return static_tables()
 
 
-@pytest.mark.parametrize("name", ["flat", "skewed", "wide", "narrow16"])
+@pytest.mark.parametrize("name", ["flat", "skewed", "wide", "narrow16", "full16", "mid17"])
 def test_static_model_matches_oracle(rx, name):
     """the coder core under a fixed frequency table.  Every block's stream equals
     the oracle's compress with the same static model (the codec is the reference's, the model is

@@ -188,6 +188,14 @@ def static_tables():
     t["wide"] = ((8, 30, 32), [0] + [sum(g[: i + 1]) for i in range(257)])
     h = [1 + (i % 7) * 9 for i in range(257)]                           # total < 2^14 - 1 for 16-bit codes
     t["narrow16"] = ((8, 14, 16), [0] + [sum(h[: i + 1]) for i in range(257)])
+    # total exactly 2^16: the largest table the device decodes by direct lookup (one byte per code value)
+    k = [1 + (i * i) % 499 for i in range(257)]
+    k[0] += 65536 - sum(k)
+    t["full16"] = ((8, 30, 32), [0] + [sum(k[: i + 1]) for i in range(257)])
+    # 2^16 < total < 2^17: too large for the lookup, small enough for the division without fix-up (the Fenwick-form descent)
+    m = [1 + (i * 37) % 700 for i in range(257)]
+    t["mid17"] = ((8, 30, 32), [0] + [sum(m[: i + 1]) for i in range(257)])
+    assert t["full16"][1][257] == 65536 and min(k) >= 1 and 65536 < t["mid17"][1][257] < (1 << 17)
     return t
 
 
