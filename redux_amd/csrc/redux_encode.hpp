@@ -447,7 +447,7 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
     // (Keeping the symbols the mask loads extracted, 8 registers, instead of extracting them again here: one VALU
     // instruction fewer per symbol and 0.9 % slower, profiles/r02_masktable/ab.txt.)
     // software pipeline: symbol i+1's LDS ops are in flight while symbol i's sums are formed
-    // (depths 2 and 3 measured no faster: the pair is bound by the VALU instructions of both waves, not by LDS latency)
+    // (depths 2 and 3 measured no faster in round 1 and slower with the mask table, 11.37 / 11.72 against 11.02 ms: LDS latency is not what the model wave waits for)
     constexpr int D = REDUX_MODEL_DEPTH;
     Tree<true>::Nodes q[D + 1];
     uint2             held = make_uint2(0, 0); // REDUX_RING_PAIRS: the even symbol of a pair, until the odd one is done
