@@ -159,6 +159,31 @@ def test_stress_patterns(rx, name):  # pending-run / carry and freeze corner cas
         assert dec[: int(sizes[0])].tobytes() == data, (name, w)
 
 
+def test_every_byte_value_in_both_lane_halves(rx):
+    """The pair kernel's model wave takes its dot-product masks from a table row per byte value (rows s and s + 1; row 256
+    is all zero, the node-256 term is added separately) and lanes l / l + 32 own the two halves of every tree dword:
+    128 blocks = two full waves in which every lane sees every byte value, runs of 255 and of 0, at its own phase."""
+    nb = 128
+    i = np.arange(BLOCK, dtype=np.int64)
+    blocks = []
+    for b in range(nb):
+        d = ((i * (2 * b + 1) + 37 * b) & 0xFF).astype(np.uint8)
+        d[1000 + 16 * b: 1400 + 16 * b] = 255
+        d[30000 + b: 30300 + b] = 0
+        d[-(b + 1):] = 255                      # the block's last symbols, whose update is skipped
+        blocks.append(d)
+    data = np.concatenate(blocks).tobytes()
+    for w in (WIDTHS[2], (8, 14, 16)):          # (8,14,16) freezes inside the block: the frozen chunks read the same table
+        out, offs, st = rx.compress_blocks(data, BLOCK, w)
+        want, _ = ox.compress_blocks(data, BLOCK, w, nthreads=8, slot=200000)
+        got = split(out, offs)
+        assert len(got) == nb
+        for b in range(nb):
+            assert got[b] == want[b], (w, b)
+        dec, sizes, _ = rx.decompress_blocks(out, offs, BLOCK, w)
+        assert all(int(x) == BLOCK for x in sizes) and dec.tobytes() == data
+
+
 def test_random_param_sweep(rx):
     rnd = np.random.default_rng(99)
     for trial in range(12):
