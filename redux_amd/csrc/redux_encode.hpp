@@ -360,6 +360,12 @@ constexpr int kPairStride = (REDUX_ROWS ? 256 : 4) | (REDUX_PAIR_SWAP ? kSwapped
 #ifndef REDUX_ONE_WAIT
 #define REDUX_ONE_WAIT 1
 #endif
+#ifndef REDUX_PERM_ADDENDS
+#define REDUX_PERM_ADDENDS 1
+#endif
+#ifndef REDUX_MASK_BUFFER
+#define REDUX_MASK_BUFFER REDUX_PERM_ADDENDS
+#endif
 // 1: the ring holds the (low, high) pairs of two consecutive symbols side by side (16 bytes per lane), written by one
 // ds_write_b128 per two symbols and read by one ds_read_b128; 0: one 8-byte entry per symbol.
 #ifndef REDUX_RING_PAIRS
@@ -387,8 +393,14 @@ static_assert(16 % REDUX_MASK_AHEAD == 0, "slot i % AHEAD must mean the same in 
 struct MaskPipe {
     uint4    s[REDUX_MASK_AHEAD], m[REDUX_MASK_AHEAD];
     uint32_t four; // the constant 4 in a VGPR: SDWA has no inline constants on gfx9
+#if REDUX_MASK_BUFFER
+    __amdgpu_buffer_rsrc_t rsrc; // k_mask_table as a raw buffer (257 rows of 16 bytes)
+#endif
     __device__ __forceinline__ void init()
     {
+#if REDUX_MASK_BUFFER
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(k_mask_table.v), 0, sizeof k_mask_table.v, 0x00027000);
+#endif
         four = 4;
         asm volatile("" : "+v"(four));
     }
@@ -414,8 +426,17 @@ struct MaskPipe {
     __device__ __forceinline__ void load(int slot, uint32_t row) // row = 16 * symbol
     {
         const char *e = reinterpret_cast<const char *>(k_mask_table.v) + row;
-        s[slot]       = *reinterpret_cast<const uint4 *>(e);
-        m[slot]       = *reinterpret_cast<const uint4 *>(e + 16);
+#if REDUX_MASK_BUFFER
+        // (as buffer loads: a plain 16-byte load whose dwords are used in two places -- addends and sums -- is split by
+        // the compiler into a 12- and a 4-byte gather, and the texture-address path pays per gather; the intrinsic stays whole)
+        (void)e;
+        const auto r0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row, 0, 0), r1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row + 16u, 0, 0);
+        s[slot] = make_uint4(r0[0], r0[1], r0[2], r0[3]);
+        m[slot] = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+#else
+        s[slot] = *reinterpret_cast<const uint4 *>(e);
+        m[slot] = *reinterpret_cast<const uint4 *>(e + 16);
+#endif
         const uint32_t sym = row >> 4; // (only the probe below uses it)
 #ifdef REDUX_PROBE_VMEM // experiment: N more 16-byte gathers per symbol, into accumulation registers nothing else uses
         if (REDUX_PROBE_VMEM >= 1)
@@ -451,9 +472,11 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
     constexpr int D = REDUX_MODEL_DEPTH;
     Tree<true>::Nodes q[D + 1];
     uint2             held = make_uint2(0, 0); // REDUX_RING_PAIRS: the even symbol of a pair, until the odd one is done
+    // (REDUX_PERM_ADDENDS: the adapting model takes its addends from the symbol's masks, Tree::issue_masked)
+    constexpr bool kMasked = REDUX_PERM_ADDENDS && REDUX_MASK_TABLE && UPD && REDUX_TOP_REG && D == 1;
 #pragma unroll
     for (int d = 0; d < D; d++)
-        q[d] = T.template issue<UPD>(sym(d), true, top);
+        q[d] = kMasked ? T.issue_masked(sym(d), mp.s[d % REDUX_MASK_AHEAD], top) : T.template issue<UPD>(sym(d), true, top);
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const uint32_t s   = sym(i);
@@ -463,7 +486,7 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
         // complete in order, so lgkmcnt <= 8 means the ring half is written).
         const bool late = REDUX_KEEP8 && i == 7;
         if (i + D < 16 && !late) {
-            q[D] = T.template issue<UPD>(sym(i + D), true, top);
+            q[D] = kMasked ? T.issue_masked(sym(i + D), mp.s[(i + D) % REDUX_MASK_AHEAD], top) : T.template issue<UPD>(sym(i + D), true, top);
             __builtin_amdgcn_sched_barrier(0);
         }
         // One hand-placed s_waitcnt for all seven node values of symbol i -- the ring write of i - 1 and the seven
@@ -510,7 +533,7 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
 #endif
         if (late) {
             __builtin_amdgcn_sched_barrier(0);
-            q[D] = T.template issue<UPD>(sym(i + D), true, top);
+            q[D] = kMasked ? T.issue_masked(sym(i + D), mp.s[(i + D) % REDUX_MASK_AHEAD], top) : T.template issue<UPD>(sym(i + D), true, top);
             if (kInFlight == 7)
                 asm volatile("s_waitcnt lgkmcnt(7)\n\ts_barrier" ::: "memory");
             else
