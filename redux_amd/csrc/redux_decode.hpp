@@ -464,9 +464,6 @@ __device__ __forceinline__ void dec_update(uint32_t *lds, const uint32_t (&A)[8]
 // (checked exhaustively on the device by redux_debug_rcp_check, tests/test_gpu_parity.py), so
 // (1 - 2^-21)/xd <= r' <= 1/xd and, the quotient being < 2^17.1, the truncated product is q or
 // q - 1; one exact f64 remainder (fma; v * xd < 2^50) adds the 1 back.
-#ifndef REDUX_DEC_PIN_FIX
-#define REDUX_DEC_PIN_FIX 0
-#endif
 __device__ __forceinline__ uint32_t dec_value(double R1d, uint32_t Vd, double cd, double cdm1)
 {
     const double xd = R1d + 1.0;
@@ -478,13 +475,11 @@ __device__ __forceinline__ uint32_t dec_value(double R1d, uint32_t Vd, double cd
 #else
     uint32_t v = (uint32_t)(nd * (__builtin_amdgcn_rcp(xd) * 0.99999976158142089844)); // 1 - 2^-22
 #endif
-#if REDUX_DEC_PIN_FIX // experiment: the correction as a 0 / 1 register, so that the comparison's VCC dies at once
-    uint32_t fix = __builtin_fma(-(double)v, xd, nd) >= xd ? 1u : 0u;
-    asm volatile("" : "+v"(fix));
-    v += fix;
-#else
+    // (Left as it is on purpose: the compiler keeps the uncorrected quotient and the comparison's VCC alive through the
+    // search and forms ~v, -v and v + 1 with carry-in instructions.  Pinning v, or only the correction bit, into a register
+    // frees VCC for the probes' carries (16 eight-byte encodings fewer per step) and is 0.6 - 0.9 ms slower,
+    // profiles/r02_decode/pair_experiment.txt.)
     v += __builtin_fma(-(double)v, xd, nd) >= xd ? 1u : 0u;
-#endif
     return v;
 }
 
