@@ -991,6 +991,11 @@ template <bool CB32>
 __global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
 {
     __shared__ uint32_t lds[128 * 64 + 32 * 64]; // tree (32 KiB) + stream ring (8 KiB): four groups fill the CU's 160 KiB
+    // One wave per SIMD, by construction: the LDS admits four of these workgroups on a CU but says nothing about which
+    // SIMDs they land on, and two lock-step waves on one SIMD take ~1.6 x as long (section 4.0, "placement").  Claiming an
+    // accumulation register beyond the half-file mark makes the descriptor ask for more than 256 registers.  (The kernel
+    // used to do that by accident of its allocation, 257 -- a variant with two stream chunks in flight needs 143.)
+    asm volatile("" ::: "a255");
     decode_lock_body<CB32, 0>(a, lds, nullptr, 0.0);
 }
 
