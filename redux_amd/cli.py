@@ -73,15 +73,10 @@ def main(argv=None):
                 i_n, o_n = len(data), len(blob)
             print("Compressed %d bytes into %d bytes, ratio: %.3f" % (i_n, o_n, i_n / o_n), file=sys.stderr)
         else:
-            # A container is recognised by a well-formed HEADER, not by its magic alone: a raw
-            # reference stream may begin with the same four bytes.
-            is_container = False
-            if data[:4] == container.MAGIC:
-                try:
-                    container.unpack(data)
-                    is_container = True
-                except api.Error:
-                    is_container = False
+            # A container is recognised by a well-formed HEADER, not by its magic alone: a raw reference
+            # stream may begin with the same four bytes.  Once the header is consistent the input IS a
+            # container: a truncated or damaged body is reported as such (exit 3), not decoded as garbage.
+            is_container = container.header_is_wellformed(data)
             if is_container:
                 out = container.decompress_bytes(data)
                 sink.write(out)

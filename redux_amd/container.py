@@ -65,6 +65,25 @@ def unpack(buf):
     return P, block_size, total, offsets, payload
 
 
+def header_is_wellformed(buf):
+    """True when the first 32 bytes are a consistent container header: magic, version, a triple
+    Parameters::new accepts, a block size in range and a block count that matches the declared
+    length.  The CLI uses it to tell a container from a raw reference stream that happens to begin
+    with the same four bytes: a well-formed header followed by a damaged or truncated body is a
+    damaged CONTAINER (unpack's error is reported), not a raw stream."""
+    b = memoryview(buf)
+    if len(b) < HEADER.size:
+        return False
+    magic, ver, sb, fb, cb, block_size, res, nblocks, total = HEADER.unpack_from(b, 0)
+    if magic != MAGIC or ver != VERSION or res != 0 or not 0 < block_size <= MAX_BLOCK_SIZE:
+        return False
+    try:
+        api.Parameters.new(sb, fb, cb)
+    except api.Error:
+        return False
+    return nblocks == (1 if total == 0 else (total + block_size - 1) // block_size)
+
+
 def compress_bytes(data, block_size=65536, params=(8, 30, 32)):
     """bytes -> container bytes (every block coded on the GPU)."""
     if not 0 < block_size <= MAX_BLOCK_SIZE:
@@ -83,7 +102,10 @@ def decompress_bytes(buf):
     if len(payload) < nb:
         raise api.InvalidInput()
     cap = max(1, min(block_size, total))  # one short block never needs block_size bytes of capacity
-    out, sizes, _ = api.decompress_blocks(payload, offsets, cap, P)
+    try:
+        out, sizes, _ = api.decompress_blocks(payload, offsets, cap, P)
+    except MemoryError:  # a header can declare far more output than this machine holds: malformed for our purposes
+        raise api.InvalidInput()
     expect = [min(block_size, total - b * block_size) for b in range(nb)] if total else [0]
     if [int(x) for x in sizes] != expect:
         raise api.InvalidInput()

@@ -265,42 +265,6 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
 //   * the bit reader refills without a branch: the dword at rpo is (re)loaded every step, a
 //     whole step before it can be needed, and consumed when fewer than 33 bits are left.
 // --------------------------------------------------------------------------------------
-#ifndef REDUX_DEC_DUP
-#define REDUX_DEC_DUP 0
-#endif
-#ifdef REDUX_DEC_CENSUS // diagnostic build: where each decode wave ran (tools/dec_census.py)
-__device__ uint32_t g_dec_hw[4096];
-#endif
-#ifdef REDUX_DEC_GSTAMPS // diagnostic build: two stamps per GROUP of four steps: [0] the group's preamble (retire the
-                         // stream chunk, store the output, request the next chunk), [1] its four steps
-__device__ uint64_t g_dec_ts[8];
-#define DEC_GSTAMP(i)                                                                                                  \
-    {                                                                                                                  \
-        uint64_t t_;                                                                                                   \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                   \
-        gts[i] += t_ - gt0;                                                                                            \
-        gt0 = t_;                                                                                                      \
-    }
-#else
-#define DEC_GSTAMP(i)
-#endif
-#ifdef REDUX_DEC_STAMPS // diagnostic build: cycle stamps inside the lock-step step (tools/dec_stamps.sh)
-__device__ uint64_t g_dec_ts[8];
-#define DEC_STAMP(i, dep)                                                                                              \
-    {                                                                                                                  \
-        uint64_t t_;                                                                                                   \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");                        \
-        dec_ts[i] += t_ - dec_t0;                                                                                      \
-        dec_t0 = t_;                                                                                                   \
-    }
-#define DEC_STAMP_ARGS , uint64_t (&dec_ts)[8], uint64_t &dec_t0
-#define DEC_STAMP_PASS , dec_ts, dec_t0
-#else
-#define DEC_STAMP(i, dep)
-#define DEC_STAMP_ARGS
-#define DEC_STAMP_PASS
-#endif
-
 struct DecFound {
     uint32_t s, lo, hi;
     uint32_t eofq; // top bit set: v >= count - 1, the first probe of get_symbol fails -> EOF (adaptive_tree.rs:116)
@@ -319,8 +283,7 @@ __device__ __forceinline__ DecTop dec_top_new() { return {128u, 64u, 64u, 32u, 3
 // get_symbol (adaptive_tree.rs:115-136) + the high end of get_frequency (:105-113), layout above.
 // Safe for any v (lanes that are already done run it on garbage): every address stays inside
 // the 32 KiB tree.
-__device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, const DecTop &T, uint32_t v,
-                                               uint32_t c DEC_STAMP_ARGS)
+__device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, const DecTop &T, uint32_t v, uint32_t c)
 {
     auto ld = [&](uint32_t byte) { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + byte); };
     uint32_t q = ~v, hq = q + (c - 1u), bits = 0, q2;
@@ -338,7 +301,6 @@ __device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, 
     REDUX_DEC_LEVEL(x6)
     const uint32_t x5 = left ? c5l : c5r;
     REDUX_DEC_LEVEL(x5)
-    DEC_STAMP(2, bits)
     // round B: levels 4, 3 under the prefix i = bits << 5: nodes i+16; i+8, i+24 (three dwords)
     uint32_t       ib  = ((bits & 7u) << 12) | L;
     const uint32_t w16 = ld(ib + (16u << 7));
@@ -346,7 +308,6 @@ __device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, 
     REDUX_DEC_LEVEL((w16 & 0xFFFFu) + 16u)
     const uint32_t x3 = left ? w8 : w24;
     REDUX_DEC_LEVEL((x3 & 0xFFFFu) + 8u)
-    DEC_STAMP(3, bits)
     // round C: levels 2, 1, 0 under i = bits << 3.  The four dwords i/2 .. i/2+3 hold nodes
     // (i, i+1), (i+2, i+3), (i+4, i+5), (i+6, i+7): all seven candidates.
     ib                = ((bits & 31u) << 10) | L;
@@ -357,7 +318,6 @@ __device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, 
     REDUX_DEC_LEVEL((e1 & 0xFFFFu) + 2u)
     const uint32_t x0 = left ? e0 : e1;  // ... if it goes right: node i+3 or i+7, the high half of level 1's dword
     REDUX_DEC_LEVEL((x0 >> 16) + 1u)
-    DEC_STAMP(4, bits)
 #undef REDUX_DEC_LEVEL
     f.s  = bits & 0xFFu;
     f.lo = v + q + 1u;  // v - rem
@@ -505,7 +465,6 @@ struct DecLane {
     uint32_t obuf;
     uint32_t n_out;      // symbols emitted: set when the block finishes (a live lane has emitted one per step)
     uint32_t dflag;      // 0x80000000 once the block is finished (EOF symbol or error)
-    uint32_t sbits;      // stream length in bits while the block is live, 0 once it is finished
     int32_t  st;
 };
 
@@ -522,7 +481,6 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
         return;
     if ((int32_t)f.eofq < 0) { // codec.rs:136-138: returns before any renormalisation
         S.dflag = 0x80000000u;
-        S.sbits = 0;
         S.n_out = p;
         return;
     }
@@ -544,7 +502,6 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
     if (S.consumed > stream_bits) { // read_bits would return Err(Eof) (bitio/mod.rs:107)
         S.st    = REDUX_EOF;
         S.dflag = 0x80000000u;
-        S.sbits = 0;
         S.n_out = p;
         return;
     }
@@ -554,7 +511,6 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
     if (!room) {
         S.st    = REDUX_OUTPUT_TOO_SMALL;
         S.dflag = 0x80000000u;
-        S.sbits = 0;
         S.n_out = p;
         return;
     }
@@ -685,7 +641,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
         S.st    = REDUX_EOF;
         S.dflag = 0x80000000u;
     }
-    S.sbits = (int32_t)S.dflag < 0 ? 0u : stream_bits;
     S.n_out = 0;
     S.obuf  = 0;
     uint32_t stored = 0; // bytes [0, stored) of the block are in memory
@@ -698,11 +653,7 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                    lds[dec_static_slot(96)], lds[dec_static_slot(160)], lds[dec_static_slot(224)]};
     const uint32_t cum256  = STATIC ? cum[256] : 0u;
     const uint32_t c_const = STATIC ? cum[257] : 0u; // total_frequency() of the static model
-#ifdef REDUX_DEC_STAMPS
-#define REDUX_DEC_SEARCH(v_, c_) (MODE == 2 ? dec_search_lut(lut, ctab, v_, cum256) : MODE == 1 ? dec_search_static(lds, T, v_, cum256) : dec_search(lds, L, T, v_, c_, dec_ts, dec_t0))
-#else
 #define REDUX_DEC_SEARCH(v_, c_) (MODE == 2 ? dec_search_lut(lut, ctab, v_, cum256) : MODE == 1 ? dec_search_static(lds, T, v_, cum256) : dec_search(lds, L, T, v_, c_))
-#endif
 
 #define REDUX_DEC_READER                                                                                               \
     {                                                                                                                  \
@@ -762,25 +713,26 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     }
 
     // ---------------- lock-step groups of four symbols ----------------
-    // While p < min(capacity, freeze point) every step updates the model and has room for its
-    // symbol.  A step is computed for all 64 lanes; if no lane is finished, reaches the EOF
-    // symbol, collapses to low == high or runs out of stream (one v_or3 + one compare on sign
-    // bits), it is committed without predication; otherwise the careful per-lane commit runs.
+    // While p < min(capacity, freeze point) every step updates the model and has room for its symbol.  A step is
+    // computed AND committed for all 64 lanes without predication; the only things that can end a block here -- the EOF
+    // symbol (codec.rs:136-138) and a stream that runs dry in the renormalisation (bitio/mod.rs:107) -- are terminal, so
+    // a lane they happen to records its result in a small exec-masked block and from then on computes on garbage that
+    // nobody reads (every address it forms stays inside its own tree column, ring column and stream buffer).
+    //
+    // A decoder wave is alone on its SIMD (the LDS holds four groups per CU), so nothing hides its two LDS round trips
+    // per step but its own instructions.  The step is therefore laid out by hand (sched_barrier pins the phases):
+    //   A  code value (codec.rs:129-131)
+    //   B  levels 7-5 of get_symbol from registers; the three candidate loads of levels 4, 3
+    //      | in their shadow: the register levels' share of update() -- it needs the top three bits of the symbol
+    //      | only -- and the bit reader's refill for this step
+    //   C  levels 4, 3; the four candidate loads of levels 2-0
+    //      | in their shadow: the update of the level-4 and level-3 nodes (their addresses are two of the three just
+    //      | loaded from), the narrowing's common factor
+    //   D  levels 2-0, narrowing, renormalisation in closed form
+    //   E  update of the level 2-0 nodes, new interval, new code value
     const uint32_t pfast = STATIC ? capn : (capn < nfreeze ? capn : nfreeze);
-#ifdef REDUX_DEC_CENSUS
-    if (lane == 0 && blockIdx.x < 4096) {
-        uint32_t hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_dec_hw[blockIdx.x] = 0x80000000u | ((xcc & 0xFu) << 16) | (hwid & 0xFFFFu);
-    }
-#endif
-#ifdef REDUX_DEC_STAMPS
-    uint64_t dec_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dec_t0 = clock64();
-#endif
-#ifdef REDUX_DEC_GSTAMPS
-    uint64_t gts[2] = {0, 0}, gt0 = clock64();
-#endif
+    uint32_t livemask = (int32_t)S.dflag < 0 ? 0x7FFFFFFFu : 0xFFFFFFFFu; // sign bit cleared once the block is finished
+    uint32_t fin_obuf = 0, fin_cons = S.consumed;                         // what a lane that finishes in this loop ends with
     if (aligned4) {
         double cdm1 = STATIC ? (double)(c_const - 1u) : 256.0, cd = STATIC ? (double)c_const : 257.0;
         // The group's four reciprocals are loaded a group ahead with VECTOR loads (every lane the
@@ -792,154 +744,191 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
         const grc4 rcv = (grc4)(uintptr_t)a.rc; // 256-byte aligned workspace, p a multiple of 4
         f64x4      rcg = STATIC ? f64x4{rc_static, rc_static, rc_static, rc_static} : rcv[0], rcn;
         asm volatile("" : "+v"(rcg)); // arrived before the loop: no in-loop wait inherits this load
+        auto ld = [&](uint32_t byte) { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + byte); };
+        auto bump = [&](uint32_t byte, uint32_t inc) {
+            __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + byte), inc, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+#define REDUX_DEC_LEVEL(t)                                                                                             \
+    left = __builtin_uadd_overflow(q, (t), &q2); /* carries exactly when the probe fails (rem < t: go left) */          \
+    bits = __builtin_amdgcn_alignbit(bits, q2, 31);                                                                    \
+    q    = q > q2 ? q : q2;                                                                                            \
+    hq   = hq < q2 ? hq : q2;
         for (; p + 4 <= pfast; p += 4) {
             if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
                 break;
-            DEC_GSTAMP(1)
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
             REDUX_DEC_REQUEST
             rcn = STATIC ? rcg : rcv[(p >> 2) + 1]; // the table has 32 entries of slack (geometry())
-            DEC_GSTAMP(0)
 #pragma unroll
             for (int K = 0; K < 4; K++) {
                 const double   rc = rcg[K];
                 const uint32_t c  = STATIC ? c_const : 257u + p + K;
-#if REDUX_DEC_DUP == 6 // what the bit reader costs: the same instructions once more on copies
-                {
-                    uint64_t bb = S.bbits; uint32_t bc = S.bcnt, rp2 = rpo, fe = fetched;
-                    asm volatile("" : "+v"(bb), "+v"(bc), "+v"(rp2), "+v"(fe));
-                    const bool     need = bc <= 32;
-                    const uint64_t add  = (uint64_t)(need ? __builtin_bswap32(fe) : 0u) << ((32 - bc) & 63);
-                    bb |= add; bc += need ? 32u : 0u; rp2 += need ? 1u : 0u;
-                    fe = ring_read(rp2);
-                    asm volatile("" ::"v"(bb), "v"(bc), "v"(rp2), "v"(fe));
-                }
-#endif
-                REDUX_DEC_READER
-                DEC_STAMP(0, S.bcnt)
+                // ---- A: code value
                 const uint32_t R1  = (~(S.ihigh + S.low)) >> sh;
                 const uint32_t Vd  = (S.W - S.low) >> sh;
                 const double   R1d = (double)R1;
-#if REDUX_DEC_DUP == 1 // timing experiments: run one part of the step twice, results unchanged
-                uint32_t Vd_ = Vd;
-                {
-                    const uint32_t v0 = dec_value(R1d, Vd, cd, cdm1);
-                    asm volatile("" : "+v"(Vd_) : "v"(v0));
-                }
-                const uint32_t v = dec_value(R1d, Vd_, cd, cdm1);
-#else
                 const uint32_t v   = dec_value(R1d, Vd, cd, cdm1);
-#endif
-                DEC_STAMP(1, v)
-#if REDUX_DEC_DUP == 2
-                uint32_t v_ = v;
-                {
-                    const DecFound f0 = REDUX_DEC_SEARCH(v, c);
-                    asm volatile("" : "+v"(v_) : "v"(f0.s), "v"(f0.lo), "v"(f0.hi));
+                // ---- B: get_symbol, first round
+                uint32_t q = ~v, hq = q + (STATIC ? cum256 : c - 1u), bits = 0, q2;
+                uint32_t eofq = hq; // top bit set: v >= count - 1 -> the EOF symbol (adaptive_tree.rs:116)
+                bool     left, l4 = false, l2 = false, l1 = false;
+                uint32_t ibB = 0, ibC = 0, a3 = 0, sym = 0;
+                uint32_t w16 = 0, w8 = 0, w24 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, n5 = 0, n6 = 0, n7 = 0;
+                if constexpr (MODE == 2) {
+                    eofq = cum256 - 1u - v;
+                    sym  = lut[v & 0xFFFFu]; // (a finished lane's v is garbage: stay inside the table)
+                } else {
+                    REDUX_DEC_LEVEL(T.n128)
+                    const uint32_t x6 = left ? T.n64 : T.n192, c5l = left ? T.n32 : T.n160, c5r = left ? T.n96 : T.n224;
+                    REDUX_DEC_LEVEL(x6)
+                    const uint32_t x5 = left ? c5l : c5r;
+                    REDUX_DEC_LEVEL(x5)
+                    if constexpr (MODE == 0) {
+                        ibB = (bits << 12) | L; // prefix i = bits << 5: nodes i+16; i+8, i+24 (three dwords)
+                        w16 = ld(ibB + (16u << 7));
+                        w8  = ld(ibB + (8u << 7));
+                        w24 = ld(ibB + (24u << 7));
+                    } else {
+                        const uint32_t *r = lds + bits * 33u; // prefix i = bits << 5 at dword i + (i >> 5)
+                        w16 = r[16]; w8 = r[8]; w24 = r[24];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- B's shadow (1): update(s+1), adaptive_tree.rs:83-92, for the levels kept in registers: node e
+                    // of level b is incremented iff s is in [e - 2^b, e), which the top three bits of s decide.
+                    // (The copy of the bits made opaque HERE and the pin below keep this block between the loads and
+                    // their first use: the compiler would otherwise sink it to the next step, where the values are used.)
+                    if constexpr (MODE == 0) {
+                        uint32_t b3 = bits; // s >> 5
+                        asm volatile("" : "+v"(b3));
+                        T.n128 += b3 < 4u ? 1u : 0u;
+                        T.n64 += b3 < 2u ? 1u : 0u;
+                        T.n192 += (b3 - 4u) < 2u ? 1u : 0u;
+                        T.n32 += b3 == 0u ? 1u : 0u;
+                        T.n96 += b3 == 2u ? 1u : 0u;
+                        T.n160 += b3 == 4u ? 1u : 0u;
+                        T.n224 += b3 == 6u ? 1u : 0u;
+                        asm volatile("" : "+v"(T.n128), "+v"(T.n64), "+v"(T.n192), "+v"(T.n32), "+v"(T.n96), "+v"(T.n160), "+v"(T.n224));
+                    }
                 }
-                const DecFound f = REDUX_DEC_SEARCH(v_, c);
-#else
-                const DecFound f   = REDUX_DEC_SEARCH(v, c);
-#endif
-                // narrowing + renormalisation (codec.rs:133-161), all lanes
-                const double   Y      = __builtin_fma(R1d, rc, rc);
-#if REDUX_DEC_DUP == 3
-                uint32_t lo_ = f.lo;
-                {
-                    const uint32_t a0 = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
-                    const uint32_t b0 = 0u - (S.low + (scale_div<false, true>(R1, Y, f.hi, c) << sh));
-                    const uint32_t x0 = ~(a0 ^ b0);
-                    uint32_t       k0;
-                    asm("v_ffbh_u32 %0, %1" : "=v"(k0) : "v"(x0));
-                    const uint32_t t0 = ((a0 << (k0 & 31u)) & (b0 << (k0 & 31u))) << 1;
-                    const uint32_t j0 = (uint32_t)__builtin_clz(~t0);
-                    asm volatile("" : "+v"(lo_) : "v"(j0));
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- C: second round
+                uint32_t lo, hi;
+                if constexpr (MODE == 2) {
+                    lo = ctab[sym];
+                    hi = ctab[sym + 1u];
+                } else if constexpr (MODE == 0) {
+                    REDUX_DEC_LEVEL((w16 & 0xFFFFu) + 16u)
+                    l4 = left;
+                    const uint32_t x3 = left ? w8 : w24;
+                    a3 = ibB + (left ? (8u << 7) : (24u << 7));
+                    REDUX_DEC_LEVEL((x3 & 0xFFFFu) + 8u)
+                    // levels 2, 1, 0 under i = bits << 3.  The four dwords i/2 .. i/2+3 hold nodes
+                    // (i, i+1), (i+2, i+3), (i+4, i+5), (i+6, i+7): all seven candidates.
+                    ibC = (bits << 10) | L;
+                    d0 = ld(ibC); d1 = ld(ibC + 256u); d2 = ld(ibC + 512u); d3 = ld(ibC + 768u);
+                } else {
+                    REDUX_DEC_LEVEL(w16)
+                    const uint32_t x3 = left ? w8 : w24;
+                    REDUX_DEC_LEVEL(x3)
+                    const uint32_t *r4 = lds + (bits << 3) + (bits >> 2); // prefix i = bits << 3: nodes i .. i+7 inside one block of 32
+                    d0 = r4[1]; d1 = r4[2]; d2 = r4[3]; d3 = r4[4]; n5 = r4[5]; n6 = r4[6]; n7 = r4[7];
                 }
-                const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, lo_, c) << sh);
-#else
-                const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
-#endif
-                const uint32_t nihigh = 0u - (S.low + (scale_div<false, true>(R1, Y, f.hi, c) << sh));
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- C's shadow: the level-4 and level-3 nodes' update (addresses: two of round B's three), the factor
+                // both ends of the new interval share (codec.rs:133-134)
+                if constexpr (MODE == 0) {
+                    bump(ibB + (16u << 7), l4 ? 1u : 0u);
+                    bump(a3, (bits & 1u) ^ 1u);
+                }
+                // ... and the bit reader's refill for this step (bitio/mod.rs:78-120)
+                asm volatile("" : "+v"(S.bcnt));
+                REDUX_DEC_READER
+                double Y = __builtin_fma(R1d, rc, rc);
+                if (!STATIC) {
+                    cdm1 = cd;
+                    cd += 1.0;
+                    asm volatile("" : "+v"(Y), "+v"(cd), "+v"(S.bbits), "+v"(S.bcnt));
+                } else
+                    asm volatile("" : "+v"(Y), "+v"(S.bbits), "+v"(S.bcnt));
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- D: last round, narrowing + renormalisation (codec.rs:133-161)
+                if constexpr (MODE == 0) {
+                    REDUX_DEC_LEVEL((d2 & 0xFFFFu) + 4u) // node i+4
+                    l2 = left;
+                    const uint32_t e1 = left ? d1 : d3;  // level 1: node i+2 or i+6 (low halves)
+                    const uint32_t e0 = left ? d0 : d2;  // level 0 if level 1 goes left: node i+1 or i+5 (high halves)
+                    REDUX_DEC_LEVEL((e1 & 0xFFFFu) + 2u)
+                    l1 = left;
+                    const uint32_t x0 = left ? e0 : e1;  // ... if it goes right: node i+3 or i+7, the high half of level 1's dword
+                    REDUX_DEC_LEVEL((x0 >> 16) + 1u)
+                } else if constexpr (MODE == 1) {
+                    REDUX_DEC_LEVEL(d3)                  // node i+4
+                    const uint32_t e1  = left ? d1 : n6; // level 1: node i+2 or i+6
+                    const uint32_t e0l = left ? d0 : n5, e0r = left ? d2 : n7; // level 0: i+1 / i+5 or i+3 / i+7
+                    REDUX_DEC_LEVEL(e1)
+                    const uint32_t x0 = left ? e0l : e0r;
+                    REDUX_DEC_LEVEL(x0)
+                }
+                if constexpr (MODE != 2) {
+                    sym = bits & 0xFFu;
+                    lo  = v + q + 1u;  // v - rem = cum(s)
+                    hi  = v + hq + 1u; // cum(s + 1): the upper boundary of the last level that went left
+                }
+                const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, lo, c) << sh);
+                const uint32_t nihigh = 0u - (S.low + (scale_div<false, true>(R1, Y, hi, c) << sh));
                 const uint32_t xx     = ~(nlow ^ nihigh);
                 uint32_t       k;
-                asm("v_ffbh_u32 %0, %1" : "=v"(k) : "v"(xx)); // -1 (sign bit) for low == high
+                asm("v_ffbh_u32 %0, %1" : "=v"(k) : "v"(xx)); // (32-bit codes: low != high while count < 2^17; narrower ones: the
+                                                              // padding below the code differs, so k <= code_bits)
                 const uint32_t low2  = nlow << (k & 31u);
                 const uint32_t ih2   = nihigh << (k & 31u);
                 const uint32_t t2    = (low2 & ih2) << 1;
                 const uint32_t j     = (uint32_t)__builtin_clz(~t2);
-                const uint32_t n     = k + j;
-                const uint32_t cons2 = S.consumed + n;
-                // sbits is 0 for a finished lane, cons2 > 0.  Codes narrower than 32 bits: low == high shows
-                // as k == code_bits (the padding below the code differs), not as v_ffbh's -1, and the
-                // commit below takes the bit that survives the E3 steps from W alone, which is only
-                // right for k < code_bits: such a step goes to the careful commit as well.
-                const uint32_t e     = CB32 ? (f.eofq | k | (S.sbits - cons2)) : (f.eofq | (cb - 1u - k) | (S.sbits - cons2));
-                DEC_STAMP(5, e)
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)e < 0) == 0, 1)) {
-#if REDUX_DEC_DUP == 4 // what the LDS-level update costs: its address arithmetic and five more atomics (of zero)
-                    {
-                        const uint32_t ss = f.s << 7;
-                        uint32_t       dup_zero = 0;
-                        asm volatile("" : "+v"(dup_zero));
-#pragma unroll
-                        for (int b = 0; b < 5; b++) {
-                            const uint32_t keep = b ? (((0xFFu << b) & 0xFFu) << 7) : (0xFEu << 7);
-                            uint32_t       addr = (ss & keep) | A[b];
-                            uint32_t       inc  = ((~f.s) >> b) & dup_zero; // an opaque zero: a literal 0 turns the atomic into a fence
-                            asm volatile("" : "+v"(addr), "+v"(inc));
-                            __hip_atomic_fetch_add(lds + (addr >> 2), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-#endif
-#if REDUX_DEC_DUP == 5 // what the register levels' update costs (7 compare + add-with-carry pairs, results discarded)
-                    {
-                        DecTop T2 = T;
-                        uint32_t s2 = f.s;
-                        asm volatile("" : "+v"(s2));
-                        T2.n128 += s2 < 128u ? 1u : 0u; T2.n64 += s2 < 64u ? 1u : 0u; T2.n192 += (s2 - 128u) < 64u ? 1u : 0u;
-                        T2.n32 += s2 < 32u ? 1u : 0u; T2.n96 += (s2 - 64u) < 32u ? 1u : 0u; T2.n160 += (s2 - 128u) < 32u ? 1u : 0u;
-                        T2.n224 += (s2 - 192u) < 32u ? 1u : 0u;
-                        asm volatile("" ::"v"(T2.n128), "v"(T2.n64), "v"(T2.n192), "v"(T2.n32), "v"(T2.n96), "v"(T2.n160), "v"(T2.n224));
-                    }
-#endif
-                    if (!STATIC)
-                        dec_update(lds, A, T, f.s);
-                    S.low      = (low2 << j) & 0x7FFFFFFFu;
-                    S.ihigh    = (ih2 << j) & 0x7FFFFFFFu;
-                    S.consumed = cons2;
-                    const uint32_t nxt  = (uint32_t)(S.bbits >> 32);
-                    const uint64_t comb = CB32 ? (((uint64_t)S.W << 32) | nxt) : (((uint64_t)S.W << 32) | ((uint64_t)nxt << sh));
-                    const uint32_t h2   = (uint32_t)((comb << n) >> 32);
-                    const uint32_t h1   = S.W << k;
-                    S.W = ((h2 & 0x7FFFFFFFu) | (h1 & 0x80000000u)) & (0xFFFFFFFFu << sh);
-                    S.bbits <<= n;
-                    S.bcnt -= n;
-                    S.obuf |= f.s << (8 * K);
-                } else {
-                    dec_commit_careful<CB32>(S, T, f, lds, A, R1, R1d, rc, c, sh, stream_bits, p + K, !STATIC, true, true, dst);
+                const uint32_t n     = k + j; // bits pulled by get_bit (codec.rs:157)
+                const uint32_t cons0 = S.consumed, cons2 = cons0 + n;
+                const uint32_t e     = (eofq | (stream_bits - cons2)) & livemask;
+                // ---- E: commit, every lane
+                if constexpr (MODE == 0) {
+                    bump(ibC + 512u, l2 ? 1u : 0u);                                   // node i+4
+                    bump(ibC + 256u + (l2 ? 0u : 512u), l1 ? 1u : 0u);                // node i+2 or i+6
+                    bump(ibC + ((sym & 6u) << 7), ((sym & 1u) ^ 1u) << 16);           // node s|1: high half of dword s >> 1
                 }
-                if (!STATIC) {
-                    cdm1 = cd;
-                    cd += 1.0;
+                S.low      = (low2 << j) & 0x7FFFFFFFu;
+                S.ihigh    = (ih2 << j) & 0x7FFFFFFFu;
+                S.consumed = cons2;
+                // [value | next 32 bits] << k, keep the top bit, << j, put it back (codec.rs:143-157).  A narrow code whose
+                // interval collapsed (k == code_bits) takes that top bit from the new bits: both shifts are 64-bit there.
+                const uint32_t nxt  = (uint32_t)(S.bbits >> 32);
+                const uint64_t comb = CB32 ? (((uint64_t)S.W << 32) | nxt) : (((uint64_t)S.W << 32) | ((uint64_t)nxt << sh));
+                const uint32_t h2   = (uint32_t)((comb << n) >> 32);
+                const uint32_t h1   = CB32 ? S.W << k : (uint32_t)((comb << k) >> 32);
+                S.W = ((h2 & 0x7FFFFFFFu) | (h1 & 0x80000000u)) & (0xFFFFFFFFu << sh);
+                S.bbits <<= n;
+                S.bcnt -= n;
+                const uint32_t obuf0 = S.obuf;
+                S.obuf = obuf0 | (sym << (8 * K));
+                // ---- the two ways a block ends here
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)e < 0) != 0, 0)) { // one scalar branch; selects inside, no exec masking
+                    const bool fin        = (int32_t)e < 0;
+                    const bool eof_symbol = (int32_t)eofq < 0; // decided first: decompress_symbol returns before renormalising
+                    S.st     = fin && !eof_symbol ? REDUX_EOF : S.st;
+                    fin_cons = fin ? (eof_symbol ? cons0 : cons2) : fin_cons;
+                    fin_obuf = fin ? obuf0 : fin_obuf;
+                    S.n_out  = fin ? p + K : S.n_out;
+                    S.dflag  = fin ? 0x80000000u : S.dflag;
+                    livemask = fin ? 0x7FFFFFFFu : livemask;
                 }
-                DEC_STAMP(6, S.low + S.W)
             }
             rcg = rcn;
         }
+#undef REDUX_DEC_LEVEL
     }
-#ifdef REDUX_DEC_STAMPS
-    if (blockIdx.x == 7 && lane == 0)
-        for (int i = 0; i < 8; i++)
-            g_dec_ts[i] = i < 7 ? dec_ts[i] : p;
-#endif
-#ifdef REDUX_DEC_GSTAMPS
-    if (blockIdx.x == 7 && lane == 0) {
-        g_dec_ts[0] = gts[0];
-        g_dec_ts[1] = gts[1];
-        g_dec_ts[7] = p;
+    if ((int32_t)S.dflag < 0) { // finished in the loop above (or never live): what the garbage steps since then did not touch
+        S.obuf     = fin_obuf;
+        S.consumed = fin_cons;
     }
-#endif
     // ---------------- remaining steps (EOF symbol, frozen model, unaligned output) ----------------
     for (;; p++) {
         if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)

@@ -25,6 +25,7 @@
 #include "../../include/redux_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -128,9 +129,13 @@ static int check_params(const redux_params *p)
 
 static bool is_any(const redux_params *p) { return p->symbol_bits != 8 || p->code_bits > 32; }
 // the widths src/model/tests.rs exercises besides 8: lock-step kernels (symbol index and byte offsets stay in 32 bits)
+// Blocks of at most 4 MiB: the kernels index a reciprocal table by the symbol number (one f64 per symbol of a block: 64 MiB
+// for 4 MiB of 4-bit symbols) and address 64 slots / 64 blocks with 32-bit lane offsets; a bigger block -- whole-stream
+// mode, redux_compress / redux_decompress of a large buffer or with a large output capacity -- is one lane's serial chain
+// anyway and runs on the one-lane kernels, which have neither limit.
 static bool is_gen(const redux_params *p, uint32_t block_size)
 {
-    return (p->symbol_bits == 4 || p->symbol_bits == 12) && p->code_bits <= 32 && block_size < (1u << 28);
+    return (p->symbol_bits == 4 || p->symbol_bits == 12) && p->code_bits <= 32 && block_size <= (1u << 22);
 }
 
 static uint64_t slot_cap_for(const redux_params *p, uint32_t block_size)
@@ -184,7 +189,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.any = !static_model && is_any(p);
     if (static_model)
         g.rc_n = 0;
-    g.gen = !static_model && is_gen(p, block_size);
+    g.gen = !static_model && is_gen(p, block_size) && 64ull * g.slot_bytes < (1ull << 32); // (64 blocks: implied by is_gen)
     if (g.gen) { // reciprocal table over the symbol count; 12-bit symbols: 4096 u32 rows x 64 lanes per wave in the workspace
         const uint64_t k0      = (1ull << p->symbol_bits) + 1;
         const uint64_t nsym    = maxlen * 8 / p->symbol_bits;
@@ -222,18 +227,20 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
         }                                                                                              \
     } while (0)
 
+// CUs of HIP's current device (the _dev entry points launch on it and keep no other state): cached per device id
 static uint32_t cu_count()
 {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0)
-            cus = 256;
+    static std::atomic<int> cus[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16)
+        return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
-    return (uint32_t)cus;
+    return (uint32_t)n;
 }
 
 // ---- which kernel a call runs: ONE decision, used by the launch code and reported by
@@ -404,9 +411,7 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
         ga.slot_cap   = g.slot_cap;
         ga.nfreeze    = g.nfreeze;
         ga.code_bits  = p->code_bits;
-        if (64ull * g.slot_bytes >= (1ull << 32) || 64ull * block_size >= (1ull << 32)) // 64 slots / blocks within a 32-bit lane offset
-            return REDUX_UNSUPPORTED;
-        const uint32_t grid = (uint32_t)((g.nblocks + 63) / 64);
+        const uint32_t grid = (uint32_t)((g.nblocks + 63) / 64); // (64 slots / blocks within a 32-bit lane offset: geometry())
         k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)(ws + g.off_rc), g.rc_n, (1u << p->symbol_bits) + 1u);
         if (p->symbol_bits == 4)
             k_encode_gen<4><<<grid, 64, 0, s>>>(ga);

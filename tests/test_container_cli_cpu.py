@@ -62,3 +62,23 @@ def test_cli_block_size_range_is_a_usage_error():
     assert cli.parse(["-c", "--block-size", "-1"]) is None
     assert cli.parse(["-c", "--block-size", str(1 << 30)])["block_size"] == 1 << 30
     assert cli.main(["-c", "--block-size", str(1 << 33)]) == 1
+
+
+def test_header_wellformedness_decides_container_vs_raw_stream(tmp_path, capsys):
+    blob = container.pack(np.zeros(4, np.uint8), np.array([0, 4], np.uint64), (8, 30, 32), 65536, 10)
+    assert container.header_is_wellformed(blob)
+    assert container.header_is_wellformed(blob[:-3])          # truncated BODY: still a container (unpack reports Eof)
+    assert not container.header_is_wellformed(blob[:20])      # truncated header: cannot be told from a raw stream
+    assert not container.header_is_wellformed(b"XXXX" + blob[4:])
+    bad = bytearray(blob)
+    bad[6] = 3                                               # Parameters::new rejects the triple
+    assert not container.header_is_wellformed(bytes(bad))
+    bad = bytearray(blob)
+    bad[16] = 2                                              # block count does not match the declared length
+    assert not container.header_is_wellformed(bytes(bad))
+    # the CLI reports a damaged container as a decompression error (exit 3) without touching the GPU:
+    # unpack() fails before any device call
+    src = tmp_path / "trunc.rdxb"
+    src.write_bytes(blob[:-3])
+    assert cli.main(["-d", "-i", str(src), "-o", str(tmp_path / "out")]) == 3
+    assert "Decompression error" in capsys.readouterr().err
