@@ -55,6 +55,14 @@ typedef struct redux_params {
     uint32_t code_bits;   /* <= 32 with symbol_bits 8: fast kernels; else general path */
 } redux_params;
 
+/* One entry of a block table (the `_v` calls below): which bytes a block is, and which entry of the
+ * per-block result tables is its.  16 bytes, host or device memory. */
+typedef struct redux_block {
+    uint64_t offset; /* encode: the block's first byte in the input buffer; decode: where its output starts */
+    uint32_t length; /* encode: bytes in the block (<= block_size); decode: output capacity (<= block_size) */
+    uint32_t index;  /* the block's number: its entry in out_offsets / in_offsets / out_sizes / block_status */
+} redux_block;
+
 /* model::Parameters::new validation, src/model/mod.rs:64: OK or INVALID_INPUT. */
 int redux_params_check(uint32_t symbol_bits, uint32_t freq_bits, uint32_t code_bits);
 /* OK, INVALID_INPUT, or UNSUPPORTED for valid triples outside the device path. */

@@ -32,6 +32,10 @@ struct DecArgs {
     uint32_t        code_bits;
     uint32_t        aligned4;   // 1: out and block_size are 4-byte multiples; 2: 16-byte multiples
     uint64_t       *in_used;    // optional: bytes of each stream the reader fetched (ByteCount, bitio/mod.rs:71)
+    // Block table (redux_decode_blocks_v_dev; null: slot j decodes block j to out + j * block_size, capacity block_size).
+    // Entry j: the block numbered `index` (its stream is in_offsets[index] .., its size / status go to entry `index`) is
+    // written at out + offset and may hold `length` <= block_size bytes.
+    const redux_block *table;
 };
 
 // BitReader (bitio/mod.rs:78-120) as a 64-bit look-ahead register: the `cnt` not yet
@@ -265,6 +269,14 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
 //   * the bit reader refills without a branch: the dword at rpo is (re)loaded every step, a
 //     whole step before it can be needed, and consumed when fewer than 33 bits are left.
 // --------------------------------------------------------------------------------------
+#ifdef REDUX_DEC_PROBE // diagnostic build (tools/variants): where a step's cycles go; never shipped
+__device__ uint64_t g_dec_probe[8];
+#define DEC_PT(v) asm volatile("s_memtime %0" : "=s"(v)::"memory")
+#define DEC_PW1(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)::"memory")
+#define DEC_PW2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory")
+#define DEC_PW3(a, b, c) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c)::"memory")
+#endif
+
 struct DecFound {
     uint32_t s, lo, hi;
     uint32_t eofq; // top bit set: v >= count - 1, the first probe of get_symbol fails -> EOF (adaptive_tree.rs:116)
@@ -469,13 +481,11 @@ struct DecLane {
 };
 
 // Per-lane, predicated end of a step: decompress_symbol after the model answered
-// (codec.rs:133-161) + decompress_stream's emission (:170-172).  `may_update`: the model is not
-// frozen; `room`: p < block capacity.
-template <bool CB32>
-__device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const DecFound &f, uint32_t *lds, const uint32_t (&A)[8],
-                                                   uint32_t R1, double R1d, double rc, uint32_t c, uint32_t sh,
-                                                   uint32_t stream_bits, uint32_t p, bool may_update, bool room,
-                                                   bool aligned4, uint8_t *dst)
+// (codec.rs:133-161) + decompress_stream's emission (:170-172).  `room`: p < block capacity.
+template <bool CB32, typename UPD>
+__device__ __forceinline__ void dec_commit_careful(DecLane &S, const DecFound &f, uint32_t R1, double R1d, double rc, uint32_t c,
+                                                   uint32_t sh, uint32_t stream_bits, uint32_t p, bool room, bool aligned4,
+                                                   uint8_t *dst, UPD &&update)
 {
     if ((int32_t)S.dflag < 0)
         return;
@@ -484,8 +494,7 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, DecTop &T, const 
         S.n_out = p;
         return;
     }
-    if (may_update)
-        dec_update(lds, A, T, f.s);
+    update(f.s); // the model's update(s+1), adaptive_tree.rs:83-92 (nothing for a frozen or static model)
     const double   Y      = __builtin_fma(R1d, rc, rc);
     const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, f.lo, c) << sh);
     const uint32_t nihigh = 0u - (S.low + (scale_div<false, true>(R1, Y, f.hi, c) << sh));
@@ -754,13 +763,28 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     bits = __builtin_amdgcn_alignbit(bits, q2, 31);                                                                    \
     q    = q > q2 ? q : q2;                                                                                            \
     hq   = hq < q2 ? hq : q2;
+#ifdef REDUX_DEC_PROBE
+        uint64_t prb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast, pg0, pg1;
+        DEC_PT(plast);
+        DEC_PW1(plast);
+#endif
         for (; p + 4 <= pfast; p += 4) {
             if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
                 break;
+#ifdef REDUX_DEC_PROBE
+            DEC_PT(pg0);
+            DEC_PW1(pg0);
+#endif
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
             REDUX_DEC_REQUEST
             rcn = STATIC ? rcg : rcv[(p >> 2) + 1]; // the table has 32 entries of slack (geometry())
+#ifdef REDUX_DEC_PROBE
+            DEC_PT(pg1);
+            DEC_PW2(pg0, pg1);
+            prb[6] += pg1 - pg0; // the group's preamble
+            prb[7] += 1;
+#endif
 #pragma unroll
             for (int K = 0; K < 4; K++) {
                 const double   rc = rcg[K];
@@ -795,6 +819,10 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                         w16 = r[16]; w8 = r[8]; w24 = r[24];
                     }
                     __builtin_amdgcn_sched_barrier(0);
+#ifdef REDUX_DEC_PROBE
+                    uint64_t pb0, pb1, pb2;
+                    DEC_PT(pb0);
+#endif
                     // ---- B's shadow (1): update(s+1), adaptive_tree.rs:83-92, for the levels kept in registers: node e
                     // of level b is incremented iff s is in [e - 2^b, e), which the top three bits of s decide.
                     // (The copy of the bits made opaque HERE and the pin below keep this block between the loads and
@@ -811,6 +839,16 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                         T.n224 += b3 == 6u ? 1u : 0u;
                         asm volatile("" : "+v"(T.n128), "+v"(T.n64), "+v"(T.n192), "+v"(T.n32), "+v"(T.n96), "+v"(T.n160), "+v"(T.n224));
                     }
+#ifdef REDUX_DEC_PROBE
+                    DEC_PT(pb1);
+                    DEC_PW2(pb0, pb1);
+                    DEC_PT(pb2);
+                    DEC_PW3(pb0, pb1, pb2);
+                    prb[0] += pb1 - pb0; // shadow B
+                    prb[1] += pb2 - pb1; // wait after shadow B (+ one stamp)
+                    prb[2] += pb0 - plast; // everything else since the previous stamp
+                    plast = pb2;
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- C: second round
@@ -836,6 +874,10 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                     d0 = r4[1]; d1 = r4[2]; d2 = r4[3]; d3 = r4[4]; n5 = r4[5]; n6 = r4[6]; n7 = r4[7];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef REDUX_DEC_PROBE
+                uint64_t pc0, pc1, pc2;
+                DEC_PT(pc0);
+#endif
                 // ---- C's shadow: the level-4 and level-3 nodes' update (addresses: two of round B's three), the factor
                 // both ends of the new interval share (codec.rs:133-134)
                 if constexpr (MODE == 0) {
@@ -852,6 +894,16 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                     asm volatile("" : "+v"(Y), "+v"(cd), "+v"(S.bbits), "+v"(S.bcnt));
                 } else
                     asm volatile("" : "+v"(Y), "+v"(S.bbits), "+v"(S.bcnt));
+#ifdef REDUX_DEC_PROBE
+                DEC_PT(pc1);
+                DEC_PW2(pc0, pc1);
+                DEC_PT(pc2);
+                DEC_PW3(pc0, pc1, pc2);
+                prb[3] += pc1 - pc0; // shadow C
+                prb[4] += pc2 - pc1; // wait after shadow C (+ one stamp)
+                prb[5] += pc0 - plast;
+                plast = pc2;
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- D: last round, narrowing + renormalisation (codec.rs:133-161)
                 if constexpr (MODE == 0) {
@@ -924,6 +976,11 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
             rcg = rcn;
         }
 #undef REDUX_DEC_LEVEL
+#ifdef REDUX_DEC_PROBE
+        if (MODE == 0 && blockIdx.x == 7 && lane == 0)
+            for (int i = 0; i < 8; i++)
+                g_dec_probe[i] = prb[i];
+#endif
     }
     if ((int32_t)S.dflag < 0) { // finished in the loop above (or never live): what the garbage steps since then did not touch
         S.obuf     = fin_obuf;
@@ -947,7 +1004,8 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
         const double   R1d = (double)R1;
         const uint32_t v   = dec_value(R1d, Vd, (double)c, (double)(c - 1u));
         const DecFound f   = REDUX_DEC_SEARCH(v, c);
-        dec_commit_careful<CB32>(S, T, f, lds, A, R1, R1d, rc, c, sh, stream_bits, p, !STATIC && p < nfreeze, p < capn, aligned4, dst);
+        dec_commit_careful<CB32>(S, f, R1, R1d, rc, c, sh, stream_bits, p, p < capn, aligned4, dst,
+                                 [&](uint32_t s) { if (!STATIC && p < nfreeze) dec_update(lds, A, T, s); });
     }
 #undef REDUX_DEC_READER
 #undef REDUX_DEC_RETIRE
@@ -974,18 +1032,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
             a.in_used[blk]      = used < size ? used : size;
         }
     }
-}
-
-template <bool CB32>
-__global__ void __launch_bounds__(64) k_decode_lock(DecArgs a)
-{
-    __shared__ uint32_t lds[128 * 64 + 32 * 64]; // tree (32 KiB) + stream ring (8 KiB): four groups fill the CU's 160 KiB
-    // One wave per SIMD, by construction: the LDS admits four of these workgroups on a CU but says nothing about which
-    // SIMDs they land on, and two lock-step waves on one SIMD take ~1.6 x as long (section 4.0, "placement").  Claiming an
-    // accumulation register beyond the half-file mark makes the descriptor ask for more than 256 registers.  (The kernel
-    // used to do that by accident of its allocation, 257 -- a variant with two stream chunks in flight needs 143.)
-    asm volatile("" ::: "a255");
-    decode_lock_body<CB32, 0>(a, lds, nullptr, 0.0);
 }
 
 } // namespace redux

@@ -48,7 +48,38 @@ struct EncArgs {
     uint32_t       aligned16; // in and block_size are 16-byte multiples
     uint32_t       lanes;     // live lanes per wave: 64, or 1 when 64 slots overflow 32-bit offsets
     uint32_t      *claims;    // kClaimWords words, zero at launch: k_encode_pair's per-CU role book
+    // Block table (redux_encode_blocks_v_dev; null: block b = in[b * block_size ...)).  Entry j is the block that slot j
+    // codes: its first byte is in + offset (offset < 2^32), it is `length` <= block_size bytes long, and its size and
+    // status belong to entry `index` of the output tables.
+    const redux_block *table;
 };
+
+// what a lane codes: source offset from the wave's base, length, and where its results go
+struct EncLane {
+    uint32_t soff, len;
+    uint64_t ob;
+};
+__device__ __forceinline__ EncLane enc_lane(const EncArgs &a, uint64_t blk0, uint64_t blk, uint32_t lane, bool live, const uint8_t *&wsrc)
+{
+    EncLane L;
+    if (a.table) { // (wave-uniform branch)
+        const redux_block e = a.table[live ? blk : blk0]; // dead lanes of the last wave re-read block blk0's bytes
+        wsrc   = a.in;
+        L.soff = (uint32_t)e.offset;
+        L.len  = live ? e.length : 0u;
+        L.ob   = e.index;
+    } else {
+        wsrc   = a.in + blk0 * a.block_size;
+        L.soff = live ? lane * a.block_size : 0u;
+        L.len  = 0;
+        if (live) {
+            const uint64_t rem = a.in_len - blk * a.block_size;
+            L.len              = rem < a.block_size ? (uint32_t)rem : a.block_size;
+        }
+        L.ob = blk;
+    }
+    return L;
+}
 
 __device__ __forceinline__ uint32_t wave_min(uint32_t v)
 {
@@ -110,14 +141,10 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
     Tree<U16> T;
     T.init(lds, lane);
 
-    uint32_t len = 0;
-    if (live) {
-        const uint64_t rem = a.in_len - blk * a.block_size;
-        len                = rem < a.block_size ? (uint32_t)rem : a.block_size;
-    }
     // wave-uniform bases (SGPR pairs) + 32-bit per-lane offsets
-    const uint8_t *wsrc  = a.in + blk0 * a.block_size;
-    const uint32_t soff  = live ? lane * a.block_size : 0u;
+    const uint8_t *wsrc;
+    const EncLane  EL    = enc_lane(a, blk0, blk, lane, live, wsrc);
+    const uint32_t len   = EL.len, soff = EL.soff;
     uint8_t       *wdst  = a.slots + blk0 * a.slot_bytes;
     // Dead lanes of the last wave run the same instruction stream on block blk0's bytes and
     // store into the spare slot behind the last real one, so the hot loop needs no predicate.
@@ -201,8 +228,8 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
             // EOF symbol (codec.rs:108): cum(256) = count-1, cum(257) = count
             const uint32_t shifts = encode_symbol<FIXUP>(S, c - 1, c, c, r, sh, true, wdst, limit);
             const uint32_t size   = encode_finish(S, shifts, a.code_bits, off0, wdst, limit);
-            a.sizes[blk]  = size;
-            a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+            a.sizes[EL.ob]  = size;
+            a.status[EL.ob] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
         }
     }
 }
@@ -722,13 +749,9 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
     Tree<true> T;
     T.init(lds, lane);
 
-    uint32_t len = 0;
-    if (live) {
-        const uint64_t rem = a.in_len - blk * a.block_size;
-        len                = rem < a.block_size ? (uint32_t)rem : a.block_size;
-    }
-    const uint8_t *wsrc  = a.in + blk0 * a.block_size;
-    const uint32_t soff  = live ? lane * a.block_size : 0u;
+    const uint8_t *wsrc;
+    const EncLane  EL    = enc_lane(a, blk0, blk, lane, live, wsrc);
+    const uint32_t len   = EL.len, soff = EL.soff;
 #if REDUX_ROWS
     // row-major group area: dword r of lane l at wdst + 256 r + 4 l (dead lanes own a column too).
     // The areas are an ODD number of 128-byte lines apart: all groups write row r at about the
@@ -884,8 +907,8 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
         } else if (live && p == len) {
             const uint32_t shifts = encode_symbol<FIXUP, kPairStride>(S, c - 1, c, c, r, sh, true, wdst, limit);
             const uint32_t size   = encode_finish<kPairStride>(S, shifts, a.code_bits, off0, wdst, limit);
-            a.sizes[blk]  = size;
-            a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+            a.sizes[EL.ob]  = size;
+            a.status[EL.ob] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
         }
     }
 #if REDUX_CLAIMS

@@ -18,6 +18,7 @@
 #include "redux_gen.hpp"
 #include "redux_encode.hpp"
 #include "redux_decode.hpp"
+#include "redux_decode_adaptive.hpp"
 #include "redux_pack.hpp"
 #include "redux_synth.hpp"
 #include "redux_static.hpp"
@@ -458,6 +459,7 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     a.code_bits  = p->code_bits;
     a.aligned16  = ((((uintptr_t)d_in) & 15) == 0 && (block_size & 15) == 0) ? 1 : 0;
     a.claims     = (uint32_t *)(ws + g.off_mode + 256);
+    a.table      = nullptr;
     // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset;
     // otherwise (giant blocks, whole-stream mode) one block per wave.
     a.lanes = encode_lanes(g, block_size);
@@ -514,6 +516,7 @@ static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *
     ca.nblocks    = g.nblocks;
     ca.mode       = (const uint32_t *)(ws + g.off_mode);
     ca.cap_rows   = (uint32_t)(g.slot_bytes / 4);
+    ca.table      = nullptr;
     k_compact<<<(uint32_t)g.nblocks, 256, 0, s>>>(ca);
 #if REDUX_ROWS // the mode word decides on the device which of the two does the work
     if (!g.any && g.u16) {
@@ -672,6 +675,7 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     if (a.aligned4 && (((uintptr_t)d_out) & 15) == 0 && (block_size & 15) == 0)
         a.aligned4 = 2; // 16-byte aligned blocks: the lock-step decoder stages four dwords per store
     a.in_used    = (uint64_t *)d_in_used;
+    a.table      = nullptr;
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
     switch (pick_decode_kernel(g, p)) {
     case DecKernel::LockCb32: k_decode_lock<true><<<grid, 64, 0, s>>>(a); break;
@@ -689,16 +693,10 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     return REDUX_OK;
 }
 
-#ifdef REDUX_DEC_CENSUS
-extern "C" int redux_debug_dec_census(uint32_t *out4096)
+#ifdef REDUX_DEC_PROBE
+extern "C" int redux_debug_dec_probe(uint64_t *out8)
 {
-    return (int)hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_dec_hw), 4096 * 4);
-}
-#endif
-#if defined(REDUX_DEC_STAMPS) || defined(REDUX_DEC_GSTAMPS)
-extern "C" int redux_debug_dec_stamps(uint64_t *out8)
-{
-    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dec_ts), 64);
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dec_probe), 64);
 }
 #endif
 
@@ -925,6 +923,7 @@ int redux_static_decode_blocks_dev(const redux_params *p, const uint32_t *cum, c
         if (a.aligned4 && (((uintptr_t)d_out) & 15) == 0 && (block_size & 15) == 0)
             la.d.aligned4 = 2;
         la.d.in_used    = nullptr;
+        la.d.table      = nullptr;
         la.rc           = a.rc;
         la.tab          = a.tab;
         const bool solo = grid <= 4u * cu_count(); // at most one wave per SIMD: keep the dispatcher from doubling them up

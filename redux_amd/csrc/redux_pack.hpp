@@ -259,6 +259,7 @@ struct CompactArgs {
     const uint32_t *mode;     // bit 0: row-major group areas (k_compact_rows) instead of linear slots (k_compact);
                               // bit 1: every aligned dword of a slot is byte-reversed (kSwapped, redux_coder.hpp)
     uint32_t        cap_rows; // rows of a group area
+    const redux_block *table; // block table (null: slot b holds block b): slot b holds the block numbered table[b].index
 };
 
 __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
@@ -269,12 +270,13 @@ __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
         return;
     const uint32_t bx  = (mode & 2u) ? 3u : 0u;                   // slot byte that holds stream byte i: i ^ bx
     const uint32_t sel = (mode & 2u) ? 0x00010203u : 0x03020100u; // v_perm selector that restores stream order
-    const uint64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
+    const uint64_t lb = a.table ? a.table[b].index : b;
+    const uint64_t o0 = a.offsets[lb], o1 = a.offsets[lb + 1];
     const uint32_t tid = threadIdx.x;
     if (o1 > a.out_cap) { // the dense buffer is too small for this block: report, never write
         if (tid == 0) {
-            if (a.status[b] == REDUX_OK)
-                a.status[b] = REDUX_OUTPUT_TOO_SMALL;
+            if (a.status[lb] == REDUX_OK)
+                a.status[lb] = REDUX_OUTPUT_TOO_SMALL;
             if (a.summary) {
                 atomicCAS(&a.summary[0], REDUX_OK, REDUX_OUTPUT_TOO_SMALL);
                 atomicAdd(&a.summary[1], 1);
@@ -361,15 +363,16 @@ __global__ void __launch_bounds__(256) k_compact_rows(CompactArgs a)
         uint64_t       d = 0;
         uint32_t       n = 0, sh = 0;
         if (b < a.nblocks) {
-            const uint64_t o0 = a.offsets[b], o1 = a.offsets[b + 1];
+            const uint64_t lb = a.table ? a.table[b].index : b;
+            const uint64_t o0 = a.offsets[lb], o1 = a.offsets[lb + 1];
             if (o1 <= a.out_cap) {
                 n  = (uint32_t)(o1 - o0);
                 sh = (uint32_t)((uintptr_t)(a.out + o0) & 3);
                 d  = (uint64_t)(uintptr_t)(a.out + o0) - sh;
                 atomicMax(&s_maxj, (sh + n + 3) >> 2);
             } else if (r0 == 0) { // the dense buffer is too small for this block: report, never write
-                if (a.status[b] == REDUX_OK)
-                    a.status[b] = REDUX_OUTPUT_TOO_SMALL;
+                if (a.status[lb] == REDUX_OK)
+                    a.status[lb] = REDUX_OUTPUT_TOO_SMALL;
                 if (a.summary) {
                     atomicCAS(&a.summary[0], REDUX_OK, REDUX_OUTPUT_TOO_SMALL);
                     atomicAdd(&a.summary[1], 1);
