@@ -269,14 +269,6 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
 //   * the bit reader refills without a branch: the dword at rpo is (re)loaded every step, a
 //     whole step before it can be needed, and consumed when fewer than 33 bits are left.
 // --------------------------------------------------------------------------------------
-#ifdef REDUX_DEC_PROBE // diagnostic build (tools/variants): where a step's cycles go; never shipped
-__device__ uint64_t g_dec_probe[8];
-#define DEC_PT(v) asm volatile("s_memtime %0" : "=s"(v)::"memory")
-#define DEC_PW1(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)::"memory")
-#define DEC_PW2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory")
-#define DEC_PW3(a, b, c) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c)::"memory")
-#endif
-
 struct DecFound {
     uint32_t s, lo, hi;
     uint32_t eofq; // top bit set: v >= count - 1, the first probe of get_symbol fails -> EOF (adaptive_tree.rs:116)
@@ -430,27 +422,20 @@ __device__ __forceinline__ void dec_update(uint32_t *lds, const uint32_t (&A)[8]
     dec_update_lds(lds, A, s);
 }
 
-// value = floor(((V - low + 1) * count - 1) / range) (codec.rs:129-131) in f64.  Numerator nd
-// (< 2^49) and range xd (an integer in [1, 2^32]) are exact.  r' = v_rcp_f64(xd) * (1 - 2^-22):
-// the raw v_rcp_f64 of gfx950 is within 2^-24 (measured: 2^-24.4) of 1/xd for EVERY integer xd in [1, 2^32]
-// (checked exhaustively on the device by redux_debug_rcp_check, tests/test_gpu_parity.py), so
-// (1 - 2^-21)/xd <= r' <= 1/xd and, the quotient being < 2^17.1, the truncated product is q or
-// q - 1; one exact f64 remainder (fma; v * xd < 2^50) adds the 1 back.
+// value = floor(((V - low + 1) * count - 1) / range) (codec.rs:129-131) in f64.  Numerator nd (< 2^49) and range xd (an
+// integer in [1, 2^32]) are exact.  The raw v_rcp_f64 of gfx950 is within 2^-24 (measured: 2^-24.4) of 1/xd for EVERY
+// integer xd in [1, 2^32] (checked exhaustively on the device by redux_debug_rcp_check, tests/test_gpu_parity.py), and the
+// quotient is below count < 2^17.1, so nd * rcp(xd) is within 0.0084 of it; ONE fma subtracts 2^-6 on the way, which puts
+// the estimate strictly below the quotient and less than 0.024 away: truncated it is q or q - 1 (a negative estimate
+// converts to 0 = q), and one exact f64 remainder (fma; v * xd < 2^50) adds the 1 back.
 __device__ __forceinline__ uint32_t dec_value(double R1d, uint32_t Vd, double cd, double cdm1)
 {
     const double xd = R1d + 1.0;
     const double nd = __builtin_fma((double)Vd, cd, cdm1); // (Vd+1)*c - 1, exact (< 2^49)
-#ifdef REDUX_DEC_NEWTON // the older form: one Newton step, bias 2^-40
-    double r = __builtin_amdgcn_rcp(xd);
-    r        = __builtin_fma(__builtin_fma(-xd, r, 1.0), r, r);
-    uint32_t v = (uint32_t)(nd * (r * 0.99999999999909050530));
-#else
-    uint32_t v = (uint32_t)(nd * (__builtin_amdgcn_rcp(xd) * 0.99999976158142089844)); // 1 - 2^-22
-#endif
+    uint32_t     v  = (uint32_t)__builtin_fma(nd, __builtin_amdgcn_rcp(xd), -0x1p-6);
     // (Left as it is on purpose: the compiler keeps the uncorrected quotient and the comparison's VCC alive through the
     // search and forms ~v, -v and v + 1 with carry-in instructions.  Pinning v, or only the correction bit, into a register
-    // frees VCC for the probes' carries (16 eight-byte encodings fewer per step) and is 0.6 - 0.9 ms slower,
-    // profiles/r02_decode/pair_experiment.txt.)
+    // frees VCC for the probes' carries and measured 0.6 - 0.9 ms slower, profiles/r02_decode/pair_experiment.txt.)
     v += __builtin_fma(-(double)v, xd, nd) >= xd ? 1u : 0u;
     return v;
 }
@@ -763,28 +748,13 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     bits = __builtin_amdgcn_alignbit(bits, q2, 31);                                                                    \
     q    = q > q2 ? q : q2;                                                                                            \
     hq   = hq < q2 ? hq : q2;
-#ifdef REDUX_DEC_PROBE
-        uint64_t prb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast, pg0, pg1;
-        DEC_PT(plast);
-        DEC_PW1(plast);
-#endif
         for (; p + 4 <= pfast; p += 4) {
             if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
                 break;
-#ifdef REDUX_DEC_PROBE
-            DEC_PT(pg0);
-            DEC_PW1(pg0);
-#endif
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
             REDUX_DEC_REQUEST
             rcn = STATIC ? rcg : rcv[(p >> 2) + 1]; // the table has 32 entries of slack (geometry())
-#ifdef REDUX_DEC_PROBE
-            DEC_PT(pg1);
-            DEC_PW2(pg0, pg1);
-            prb[6] += pg1 - pg0; // the group's preamble
-            prb[7] += 1;
-#endif
 #pragma unroll
             for (int K = 0; K < 4; K++) {
                 const double   rc = rcg[K];
@@ -819,10 +789,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                         w16 = r[16]; w8 = r[8]; w24 = r[24];
                     }
                     __builtin_amdgcn_sched_barrier(0);
-#ifdef REDUX_DEC_PROBE
-                    uint64_t pb0, pb1, pb2;
-                    DEC_PT(pb0);
-#endif
                     // ---- B's shadow (1): update(s+1), adaptive_tree.rs:83-92, for the levels kept in registers: node e
                     // of level b is incremented iff s is in [e - 2^b, e), which the top three bits of s decide.
                     // (The copy of the bits made opaque HERE and the pin below keep this block between the loads and
@@ -839,16 +805,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                         T.n224 += b3 == 6u ? 1u : 0u;
                         asm volatile("" : "+v"(T.n128), "+v"(T.n64), "+v"(T.n192), "+v"(T.n32), "+v"(T.n96), "+v"(T.n160), "+v"(T.n224));
                     }
-#ifdef REDUX_DEC_PROBE
-                    DEC_PT(pb1);
-                    DEC_PW2(pb0, pb1);
-                    DEC_PT(pb2);
-                    DEC_PW3(pb0, pb1, pb2);
-                    prb[0] += pb1 - pb0; // shadow B
-                    prb[1] += pb2 - pb1; // wait after shadow B (+ one stamp)
-                    prb[2] += pb0 - plast; // everything else since the previous stamp
-                    plast = pb2;
-#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- C: second round
@@ -874,10 +830,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                     d0 = r4[1]; d1 = r4[2]; d2 = r4[3]; d3 = r4[4]; n5 = r4[5]; n6 = r4[6]; n7 = r4[7];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#ifdef REDUX_DEC_PROBE
-                uint64_t pc0, pc1, pc2;
-                DEC_PT(pc0);
-#endif
                 // ---- C's shadow: the level-4 and level-3 nodes' update (addresses: two of round B's three), the factor
                 // both ends of the new interval share (codec.rs:133-134)
                 if constexpr (MODE == 0) {
@@ -894,16 +846,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                     asm volatile("" : "+v"(Y), "+v"(cd), "+v"(S.bbits), "+v"(S.bcnt));
                 } else
                     asm volatile("" : "+v"(Y), "+v"(S.bbits), "+v"(S.bcnt));
-#ifdef REDUX_DEC_PROBE
-                DEC_PT(pc1);
-                DEC_PW2(pc0, pc1);
-                DEC_PT(pc2);
-                DEC_PW3(pc0, pc1, pc2);
-                prb[3] += pc1 - pc0; // shadow C
-                prb[4] += pc2 - pc1; // wait after shadow C (+ one stamp)
-                prb[5] += pc0 - plast;
-                plast = pc2;
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- D: last round, narrowing + renormalisation (codec.rs:133-161)
                 if constexpr (MODE == 0) {
@@ -976,11 +918,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
             rcg = rcn;
         }
 #undef REDUX_DEC_LEVEL
-#ifdef REDUX_DEC_PROBE
-        if (MODE == 0 && blockIdx.x == 7 && lane == 0)
-            for (int i = 0; i < 8; i++)
-                g_dec_probe[i] = prb[i];
-#endif
     }
     if ((int32_t)S.dflag < 0) { // finished in the loop above (or never live): what the garbage steps since then did not touch
         S.obuf     = fin_obuf;

@@ -238,6 +238,19 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
         fetched = ring_read(rpo);                                                                                      \
     }
 
+    // the same in the fast loop: "fewer than 33 bits left" as a sign mask instead of a compare (no lane mask in scalar
+    // registers: two wait states between its VALU writer and its VALU reader on gfx950)
+#define REDUX_AD_READER_FAST                                                                                           \
+    {                                                                                                                  \
+        uint32_t need = (uint32_t)((int32_t)(S.bcnt - 33u) >> 31); /* all ones: refill */                              \
+        asm("" : "+v"(need));                                                                                          \
+        const uint64_t add = (uint64_t)(__builtin_bswap32(fetched) & need) << ((32 - S.bcnt) & 63);                    \
+        S.bbits |= add;                                                                                                \
+        S.bcnt += need & 32u;                                                                                          \
+        rpo -= need;                                                                                                   \
+        fetched = ring_read(rpo);                                                                                      \
+    }
+
     S.W = (uint32_t)((S.bbits >> 1) >> (63 - cb)) << sh; // codec.rs:124-127
     S.bbits <<= cb;
     S.bcnt -= cb;
@@ -287,17 +300,22 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
         asm volatile("" : "+v"(rcg)); // arrived before the loop: no in-loop wait inherits this load
         // update() of the register levels by table: bit b3 = s >> 5 of byte k says whether node k is incremented
         uint32_t kp0 = 0x0130030Fu, kp1 = 0x00401004u; // bytes: n128, n64, n192, n32 | n96, n160, n224
-        uint32_t k10001 = 0x10001u, k10000 = 0x10000u;
-        asm volatile("" : "+v"(kp0), "+v"(kp1), "+v"(k10001), "+v"(k10000));
-#define REDUX_AD_LEVEL(t)                                                                                              \
-    left = __builtin_uadd_overflow(q, (t), &q2); /* carries exactly when the probe fails (rem < t: go left) */          \
-    bits = __builtin_amdgcn_alignbit(bits, q2, 31);                                                                    \
-    q    = q > q2 ? q : q2;                                                                                            \
-    hq   = hq < q2 ? hq : q2;
+        uint32_t k10001 = 0x10001u, k10000 = 0x10000u, k01010101 = 0x01010101u;
+        asm volatile("" : "+v"(kp0), "+v"(kp1), "+v"(k10001), "+v"(k10000), "+v"(k01010101));
+        uint32_t r1 = ~(S.ihigh + S.low); // high - low of the interval, left-aligned: carried instead of ~high (see the commit)
+        // range = high - low + 1 and its reciprocal are formed at the END of a step, as soon as the new interval is known:
+        // the division chain of the next step's code value (codec.rs:131) starts under the rest of the commit
+        uint32_t R1  = r1 >> sh;
+        double   R1d = (double)R1, xd = R1d + 1.0, rinv = __builtin_amdgcn_rcp(xd);
         for (; p + 16 <= pfast; p += 16) {
             if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
                 break;
             uint32_t img[4] = {0, 0, 0, 0}; // this iteration's sixteen bytes
+            // The part of a step's commit that nothing in the same step waits for -- the octet cell's update, the stream
+            // window's shift, the output byte -- is issued at the top of the NEXT step, where the division chain of the
+            // code value leaves issue slots free (and where it shares a basic block with it: the fix-up branch at the end
+            // of a step is a scheduling boundary).
+            uint32_t t_aC = 0, t_lo = 0, t_hi = 0, t_n = 0, t_sym = 0;
 #pragma unroll
             for (int G = 0; G < 4; G++) {
                 // once per group, in this order (vmcnt counts loads AND stores, in order, so the one wait of a group
@@ -313,22 +331,53 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                 for (int K = 0; K < 4; K++) {
                     const double   rc = rcg[K];
                     const uint32_t c  = 257u + p + 4 * G + K;
-                    // ---- A: code value (codec.rs:129-131)
-                    const uint32_t R1  = (~(S.ihigh + S.low)) >> sh;
-                    const uint32_t Vd  = (S.W - S.low) >> sh;
-                    const double   R1d = (double)R1;
-                    const uint32_t v   = dec_value(R1d, Vd, cd, cdm1);
-                    // ---- B: get_symbol (adaptive_tree.rs:115-136), levels 7-5 from registers
-                    uint32_t q = ~v, hq = q + (c - 1u), bits = 0, q2;
+                    // ---- the previous step's deferred commit
+                    if (G != 0 || K != 0) {
+                        const int PG = K == 0 ? G - 1 : G, PK = K == 0 ? 3 : K - 1; // (constants once the loops are unrolled)
+                        A.bump64(t_aC, t_lo, t_hi);
+                        S.bbits <<= t_n;
+                        S.bcnt -= t_n;
+                        img[PG] = PK == 0 ? t_sym : (img[PG] | (t_sym << (8 * PK)));
+                    }
+                    // ---- the bit reader's refill for this step (bitio/mod.rs:78-120): independent of everything below until
+                    // the commit, so it fills the issue slots the division chain leaves
+                    REDUX_AD_READER_FAST
+                    // ---- A: code value (codec.rs:129-131): dec_value() with the reciprocal already at hand
+                    const uint32_t Vd = (S.W - S.low) >> sh;
+                    const double   nd = __builtin_fma((double)Vd, cd, cdm1); // (Vd+1)*c - 1, exact (< 2^49)
+                    // (quotient estimate q or q - 1, dec_value(); the correction as a sign: nd - (v0 + 1) * xd is negative iff
+                    // v0 is the quotient already)
+                    const uint32_t v0p = (uint32_t)__builtin_fma(nd, rinv, -0x1p-6) + 1u;
+                    const double   rem = __builtin_fma(-(double)v0p, xd, nd);
+                    uint32_t       fix = (uint32_t)((int32_t)(uint32_t)((uint64_t)__double_as_longlong(rem) >> 32) >> 31); // -1: no
+                    asm("" : "+v"(fix));
+                    const uint32_t v = v0p + fix;
+                    // ---- B: get_symbol (adaptive_tree.rs:115-136), levels 7-5 from registers.  No carries, no lane masks in
+                    // scalar registers: a VALU result that goes through an SGPR pair reaches the next VALU instruction two wait
+                    // states late on gfx950, and the descent is the step's serial chain.  "Went right" is the sign of q2;
+                    // spread over the dword (one shift) it selects the next candidates by v_bfi.
+                    uint32_t cm1 = c - 1u; // (one scalar register: the compiler would otherwise split it into p + a literal, two adds)
+                    asm volatile("" : "+s"(cm1));
+                    uint32_t q = ~v, hq = q + cm1, bits = 0, q2, m;
                     const uint32_t eofq = hq; // top bit set: v >= count - 1 -> the EOF symbol (adaptive_tree.rs:116)
-                    bool           left;
-                    REDUX_AD_LEVEL(T.n128)
-                    const uint32_t x6 = left ? T.n64 : T.n192, c5l = left ? T.n32 : T.n160, c5r = left ? T.n96 : T.n224;
-                    REDUX_AD_LEVEL(x6)
-                    const uint32_t x5 = left ? c5l : c5r;
-                    REDUX_AD_LEVEL(x5)
+#define REDUX_AD_STEP(t)                                                                                               \
+    q2   = q + (t);                                                                                                    \
+    bits = __builtin_amdgcn_alignbit(bits, q2, 31);                                                                    \
+    q    = q > q2 ? q : q2;                                                                                            \
+    hq   = hq < q2 ? hq : q2;
+#define REDUX_AD_MASK()                                                                                                \
+    m = (uint32_t)((int32_t)q2 >> 31); /* all ones: the probe succeeded, go right */                                   \
+    asm("" : "+v"(m))                  /* (opaque: the compiler would turn the picks back into compare + v_cndmask) */
+#define REDUX_AD_PICK(l, r) ((m & (r)) | (~m & (l)))
+                    REDUX_AD_STEP(T.n128)
+                    REDUX_AD_MASK();
+                    const uint32_t x6 = REDUX_AD_PICK(T.n64, T.n192), c5l = REDUX_AD_PICK(T.n32, T.n160), c5r = REDUX_AD_PICK(T.n96, T.n224);
+                    REDUX_AD_STEP(x6)
+                    REDUX_AD_MASK();
+                    const uint32_t x5 = REDUX_AD_PICK(c5l, c5r);
+                    REDUX_AD_STEP(x5)
                     const uint32_t aB = A.bcell_addr(bits); // (bits = s >> 5)
-                    const ad_u32x2 bc = A.ld_bcell(aB);
+                    ad_u32x2 bc = A.ld_bcell(aB);
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- B's shadow: update(s+1), adaptive_tree.rs:83-92, for the levels kept in registers, which the
                     // top three bits of s decide.  (The copy of the bits made opaque HERE and the pin below keep this
@@ -336,57 +385,59 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                     {
                         uint32_t b3 = bits;
                         asm volatile("" : "+v"(b3));
-                        const uint32_t t0 = (kp0 >> b3) & 0x01010101u, t1 = (kp1 >> b3) & 0x01010101u;
-                        T.n128 += t0 & 0xFFu;
-                        T.n64 += (t0 >> 8) & 0xFFu;
-                        T.n192 += (t0 >> 16) & 0xFFu;
-                        T.n32 += t0 >> 24;
-                        T.n96 += t1 & 0xFFu;
-                        T.n160 += (t1 >> 8) & 0xFFu;
-                        T.n224 += (t1 >> 16) & 0xFFu;
-                        asm volatile("" : "+v"(T.n128), "+v"(T.n64), "+v"(T.n192), "+v"(T.n32), "+v"(T.n96), "+v"(T.n160), "+v"(T.n224));
+                        // byte k of t0 / t1 = 1 iff node k is incremented; each add takes its byte as an SDWA operand
+                        const uint32_t t0 = (kp0 >> b3) & k01010101, t1 = (kp1 >> b3) & k01010101;
+#define REDUX_AD_ADD_BYTE(n, t, B)                                                                                     \
+    asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B : "+v"(n) : "v"(t));
+                        REDUX_AD_ADD_BYTE(T.n128, t0, 0)
+                        REDUX_AD_ADD_BYTE(T.n64, t0, 1)
+                        REDUX_AD_ADD_BYTE(T.n192, t0, 2)
+                        REDUX_AD_ADD_BYTE(T.n32, t0, 3)
+                        REDUX_AD_ADD_BYTE(T.n96, t1, 0)
+                        REDUX_AD_ADD_BYTE(T.n160, t1, 1)
+                        REDUX_AD_ADD_BYTE(T.n224, t1, 2)
+#undef REDUX_AD_ADD_BYTE
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- C: levels 4, 3 from the B cell (+16 | +8, spare | +24)
-                    REDUX_AD_LEVEL(bc.x & 0xFFFFu)
-                    const bool     l4 = left;
-                    const uint32_t x3 = left ? bc.x : bc.y;
-                    REDUX_AD_LEVEL(x3 >> 16)
-                    const bool     l3 = left;
+                    REDUX_AD_STEP(bc.x & 0xFFFFu)
+                    REDUX_AD_MASK();
+                    const uint32_t m4 = m;
+                    const uint32_t x3 = REDUX_AD_PICK(bc.x, bc.y);
+                    REDUX_AD_STEP(x3 >> 16)
+                    REDUX_AD_MASK();
+                    const uint32_t m3 = m;
                     const uint32_t aC = A.octet_addr(bits); // (bits = s >> 3)
-                    const ad_u32x4 oc = A.ld_octet(aC);
+                    ad_u32x4 oc = A.ld_octet(aC);
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- C's shadow: the B cell's update (+16 iff bit 4 clear, +8 iff bits 4 and 3 clear, +24 iff bit 4
-                    // set and bit 3 clear), the bit reader's refill for this step (bitio/mod.rs:78-120), the factor both
-                    // ends of the new interval share (codec.rs:133-134)
+                    // set and bit 3 clear), the factor both ends of the new interval share (codec.rs:133-134)
                     {
-                        const uint32_t lo34 = l4 ? (l3 ? k10001 : 1u) : 0u;
-                        const uint32_t hi34 = l4 ? 0u : (l3 ? k10000 : 0u);
-                        A.bump64(aB, lo34, hi34);
+                        const uint32_t t34 = (~m3 & k10000) | 1u;
+                        A.bump64(aB, ~m4 & t34, m4 & ~m3 & k10000);
                     }
-                    asm volatile("" : "+v"(S.bcnt));
-                    REDUX_AD_READER
                     double Y = __builtin_fma(R1d, rc, rc);
                     cdm1     = cd;
                     cd += 1.0;
-                    asm volatile("" : "+v"(Y), "+v"(cd), "+v"(S.bbits), "+v"(S.bcnt));
+                    asm volatile("" : "+v"(Y), "+v"(cd));
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- D: levels 2-0 from the octet cell (+1 | +2, +3 | +4, +5 | +6, +7 | spare), narrowing and
                     // renormalisation (codec.rs:133-161)
-                    REDUX_AD_LEVEL(oc.y >> 16) // node +4
-                    const bool     l2 = left;
-                    const uint32_t u  = left ? oc.x : oc.z;
-                    const uint32_t w  = left ? oc.y : oc.w;
-                    REDUX_AD_LEVEL(u >> 16)    // node +2 or +6
-                    const bool     l1 = left;
-                    const uint32_t x0 = left ? u : w;
-                    REDUX_AD_LEVEL(x0 & 0xFFFFu) // node +1 / +5 or +3 / +7
-                    const bool     l0  = left;
+                    REDUX_AD_STEP(oc.y >> 16) // node +4
+                    REDUX_AD_MASK();
+                    const uint32_t m2 = m;
+                    const uint32_t u  = REDUX_AD_PICK(oc.x, oc.z);
+                    const uint32_t w  = REDUX_AD_PICK(oc.y, oc.w);
+                    REDUX_AD_STEP(u >> 16)    // node +2 or +6
+                    REDUX_AD_MASK();
+                    const uint32_t m1 = m;
+                    const uint32_t x0 = REDUX_AD_PICK(u, w);
+                    REDUX_AD_STEP(x0 & 0xFFFFu) // node +1 / +5 or +3 / +7
                     const uint32_t sym = bits & 0xFFu;
-                    const uint32_t lo  = v + q + 1u;  // v - rem = cum(s)
-                    const uint32_t hi  = v + hq + 1u; // cum(s + 1): the upper boundary of the last level that went left
-                    const uint32_t nlow   = S.low + (scale_div<false>(R1, Y, lo, c) << sh);
-                    const uint32_t nihigh = 0u - (S.low + (scale_div<false, true>(R1, Y, hi, c) << sh));
+                    uint32_t lo  = v + q + 1u;  // v - rem = cum(s)
+                    uint32_t hi  = v + hq + 1u; // cum(s + 1): the upper boundary of the last level that went left
+                    uint32_t nlow   = S.low + (scale_div<false>(R1, Y, lo, c) << sh);
+                    uint32_t nihigh = 0u - (S.low + (scale_div<false, true>(R1, Y, hi, c) << sh));
                     const uint32_t xx     = ~(nlow ^ nihigh);
                     uint32_t       k;
                     asm("v_ffbh_u32 %0, %1" : "=v"(k) : "v"(xx)); // (32-bit codes: low != high while count < 2^17; narrower ones:
@@ -397,19 +448,26 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                     const uint32_t j     = (uint32_t)__builtin_clz(~t2);
                     const uint32_t n     = k + j; // bits pulled by get_bit (codec.rs:157)
                     const uint32_t cons0 = S.consumed, cons2 = cons0 + n;
-                    const uint32_t e     = (eofq | (stream_bits - cons2)) & livemask;
+                    uint32_t e     = (eofq | (stream_bits - cons2)) & livemask;
                     // ---- E: commit, every lane.  The half of the octet cell that holds the quad of s: fields
                     // (+1 | +5, +2 | +6, +3 | +7, +4 | spare) get (bits 1, 0 clear; bit 1 clear; bit 1 set, bit 0 clear;
-                    // bit 2 clear)
+                    // bit 2 clear); issued at the top of the next step
                     {
-                        const uint32_t lo = l1 ? (l0 ? k10001 : k10000) : 0u;
-                        const uint32_t h2 = l2 ? k10000 : 0u;
-                        const uint32_t hi = l1 ? h2 : h2 + (l0 ? 1u : 0u);
-                        A.bump64(aC + (l2 ? 0u : 8u), lo, hi);
+                        const uint32_t r0 = sym & 1u;
+                        t_lo  = ~m1 & k10001 & ~r0;
+                        t_hi  = (~m2 & k10000) | (m1 & ~r0 & 1u);
+                        t_aC  = aC | (m2 & 8u);
+                        t_n   = n;
+                        t_sym = sym;
                     }
-                    S.low      = (low2 << j) & 0x7FFFFFFFu;
-                    S.ihigh    = (ih2 << j) & 0x7FFFFFFFu;
-                    S.consumed = cons2;
+                    // The j E3 steps drop bit 30 j times: shift by j, clear bit 31.  Bit 31 of both shifted values is the same
+                    // (j >= 1: both had ones there; j == 0: both have 0 after the k shared bits), so the next interval width
+                    // ~(low + ~high) is the same with or without the two clears: only low, which is added to, gets its clear,
+                    // and ~high is not kept at all.
+                    const uint32_t Ls = low2 << j;
+                    r1                = ~(Ls + (ih2 << j));
+                    S.low             = Ls & 0x7FFFFFFFu;
+                    S.consumed        = cons2;
                     // [value | next 32 bits] << k, keep the top bit, << j, put it back (codec.rs:143-157).  A narrow code
                     // whose interval collapsed (k == code_bits) takes that top bit from the new bits: both shifts 64-bit.
                     const uint32_t nxt  = (uint32_t)(S.bbits >> 32);
@@ -417,10 +475,11 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                     const uint32_t h2   = (uint32_t)((comb << n) >> 32);
                     const uint32_t h1   = CB32 ? S.W << k : (uint32_t)((comb << k) >> 32);
                     S.W = ((h2 & 0x7FFFFFFFu) | (h1 & 0x80000000u)) & (0xFFFFFFFFu << sh);
-                    S.bbits <<= n;
-                    S.bcnt -= n;
-                    const uint32_t img0 = img[G];
-                    img[G]              = K == 0 ? sym : (img0 | (sym << (8 * K)));
+                    R1   = r1 >> sh;
+                    R1d  = (double)R1;
+                    xd   = R1d + 1.0;
+                    rinv = __builtin_amdgcn_rcp(xd);
+                    const uint32_t img0 = img[G]; // (this step's byte joins it at the top of the next step)
                     // ---- the two ways a block ends here
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)e < 0) != 0, 0)) { // one scalar branch; selects inside
                         const bool fin        = (int32_t)e < 0;
@@ -450,18 +509,25 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                 }
                 rcg = rcn;
             }
+            A.bump64(t_aC, t_lo, t_hi); // the last step's deferred commit
+            S.bbits <<= t_n;
+            S.bcnt -= t_n;
+            img[3] |= t_sym << 24;
             // the iteration's sixteen bytes: stored at the top of the next iteration (or below)
             oq.x = (int32_t)S.dflag >= 0 ? img[0] : oq.x;
             oq.y = (int32_t)S.dflag >= 0 ? img[1] : oq.y;
             oq.z = (int32_t)S.dflag >= 0 ? img[2] : oq.z;
             oq.w = (int32_t)S.dflag >= 0 ? img[3] : oq.w;
         }
-#undef REDUX_AD_LEVEL
+#undef REDUX_AD_STEP
+#undef REDUX_AD_MASK
+#undef REDUX_AD_PICK
         if (p != 0 && (int32_t)S.dflag >= 0) {
             *reinterpret_cast<uint4 *>(dst + (p - 16)) = oq;
             stored = p;
             staged = p;
         }
+        S.ihigh = (~r1 - S.low) & 0x7FFFFFFFu; // (the predicated loop keeps ~high)
     }
     if ((int32_t)S.dflag < 0) // finished in the loop above (or never live): what the garbage steps since then did not touch
         S.consumed = fin_cons;
@@ -507,6 +573,7 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                                  [&](uint32_t s) { if (p < nfreeze) ad_update(A, T, s); });
     }
 #undef REDUX_AD_READER
+#undef REDUX_AD_READER_FAST
     if (live) {
         if (aligned4) {
             // the 0..3 staged dwords (oldest first: the last k components of oq), then the partial one

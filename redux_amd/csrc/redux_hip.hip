@@ -693,13 +693,6 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     return REDUX_OK;
 }
 
-#ifdef REDUX_DEC_PROBE
-extern "C" int redux_debug_dec_probe(uint64_t *out8)
-{
-    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dec_probe), 64);
-}
-#endif
-
 // Diagnostic (tests only): where the encoder's per-CU role book sits in the workspace.
 int redux_debug_role_book(const redux_params *p, uint64_t in_len, uint32_t block_size, uint64_t *offset, uint64_t *bytes)
 {
