@@ -1,8 +1,10 @@
 // redux_decode.hpp -- decode kernels of the MI355X block coder (gfx950 only).
 //
-//   k_decode<U16,FIXUP>  one wave per 64 blocks, per-lane control flow (general form)
-//   k_decode_lock<CB32>  default: all 64 lanes in lock-step, stream ring in LDS, top tree levels in VGPRs
-//   k_rcp_check          device-side exhaustive check of the reciprocal bound k_decode_lock relies on
+//   k_decode<U16,FIXUP>  one wave per 64 blocks, per-lane control flow (general form: u32 trees, count >= 2^17)
+//   decode_lock_body     the lock-step decoder body of the STATIC-table kernels (redux_static.hpp); shared pieces of the
+//                        adaptive lock-step decoder k_decode_lock (redux_decode_adaptive.hpp): DecArgs, DecLane, DecTop,
+//                        dec_value, dec_commit_careful
+//   k_rcp_check          device-side exhaustive check of the reciprocal bound dec_value relies on
 //
 // Included by redux_hip.hip (one translation unit).
 #pragma once
@@ -250,84 +252,24 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
 }
 
 // --------------------------------------------------------------------------------------
-// Lock-step decoder (the default for u16 trees, count < 2^17).  Same results as k_decode; what changes is the instruction count of a step, which is what a lone wave
-// per SIMD pays for:
-//   * own tree layout: lane l owns dword column l; dword k of the column holds nodes 2k (low
-//     half) and 2k+1 (high half): byte address (k << 8) | 4*l.  Levels 1-7 are even nodes, so
-//     their half is static (low); level 0 is always a high half.  No per-lane half select.
-//   * the descent keeps q = ~rem.  For a node value t, q2 = q + t is ~(rem - t): its top bit
-//     is the "go right" flag, the new q is max_u32(q, q2) (q2 wraps to a small number when the
-//     probe fails), and the flags are shifted into the symbol by v_alignbit.  cum(s+1) falls
-//     out of the same probes: it is the upper boundary of the LAST level where the descent
-//     went left, i.e. v + 1 + min_u32 over the levels of q2 (failed probes give the small
-//     values and the boundary only shrinks on the way down; the virtual root probe against
-//     tree[256] = count - 1 seeds the minimum).  Five VALU ops per level, no second masked sum.
-//   * all 64 lanes stay in lock-step while nothing exceptional happens: the step is computed
-//     for every lane, and ONE ballot (EOF symbol, low == high, stream exhausted) decides whether
-//     it is committed without predication.  The first exceptional step leaves the fast loop
-//     with nothing committed and the predicated loop below redoes it and finishes the blocks.
-//   * the bit reader refills without a branch: the dword at rpo is (re)loaded every step, a
-//     whole step before it can be needed, and consumed when fewer than 33 bits are left.
+// Pieces shared by the lock-step decoders (the adaptive one, redux_decode_adaptive.hpp, and the static-table ones below).
+// The descent keeps q = ~rem.  For a node value t, q2 = q + t is ~(rem - t): its top bit is the "go right" flag, the new
+// q is max_u32(q, q2) (q2 wraps to a small number when the probe fails), and the flags are shifted into the symbol by
+// v_alignbit.  cum(s+1) falls out of the same probes: it is the upper boundary of the LAST level where the descent went
+// left, i.e. v + 1 + min_u32 over the levels of q2 (failed probes give the small values and the boundary only shrinks on
+// the way down; the virtual root probe against tree[256] = count - 1 seeds the minimum).
 // --------------------------------------------------------------------------------------
 struct DecFound {
     uint32_t s, lo, hi;
     uint32_t eofq; // top bit set: v >= count - 1, the first probe of get_symbol fails -> EOF (adaptive_tree.rs:116)
 };
 
-// The seven nodes of levels 7, 6, 5 (128; 64, 192; 32, 96, 160, 224) are at fixed positions,
-// so a decoder lane keeps them in VGPRs: the first three probes of every descent need no LDS
-// round trip, and their updates are compare + add-with-carry instead of LDS atomics.  (A
-// lock-step decoder wave is alone on its SIMD and the four waves of a CU share one LDS
-// pipeline: 8 cycles per ds_read_b32 and 16 per ds_add, tools/ubench/lone.hip.)
+// The seven nodes of levels 7, 6, 5 (128; 64, 192; 32, 96, 160, 224) are at fixed positions, so a decoder lane keeps
+// them in VGPRs: the first three probes of every descent need no LDS round trip.
 struct DecTop {
     uint32_t n128, n64, n192, n32, n96, n160, n224; // full tree values (lowbit + increments): u32, no overflow to think about
 };
 __device__ __forceinline__ DecTop dec_top_new() { return {128u, 64u, 64u, 32u, 32u, 32u, 32u}; }
-
-// get_symbol (adaptive_tree.rs:115-136) + the high end of get_frequency (:105-113), layout above.
-// Safe for any v (lanes that are already done run it on garbage): every address stays inside
-// the 32 KiB tree.
-__device__ __forceinline__ DecFound dec_search(const uint32_t *lds, uint32_t L, const DecTop &T, uint32_t v, uint32_t c)
-{
-    auto ld = [&](uint32_t byte) { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + byte); };
-    uint32_t q = ~v, hq = q + (c - 1u), bits = 0, q2;
-    DecFound f;
-    f.eofq = hq;
-#define REDUX_DEC_LEVEL(t)                                                                                             \
-    left = __builtin_uadd_overflow(q, (t), &q2); /* carries exactly when the probe fails (rem < t: go left) */          \
-    bits = __builtin_amdgcn_alignbit(bits, q2, 31);                                                                    \
-    q    = q > q2 ? q : q2;                                                                                            \
-    hq   = hq < q2 ? hq : q2;
-    bool left;
-    // levels 7, 6, 5: registers (full tree values: lowbit + increments)
-    REDUX_DEC_LEVEL(T.n128)
-    const uint32_t x6 = left ? T.n64 : T.n192, c5l = left ? T.n32 : T.n160, c5r = left ? T.n96 : T.n224;
-    REDUX_DEC_LEVEL(x6)
-    const uint32_t x5 = left ? c5l : c5r;
-    REDUX_DEC_LEVEL(x5)
-    // round B: levels 4, 3 under the prefix i = bits << 5: nodes i+16; i+8, i+24 (three dwords)
-    uint32_t       ib  = ((bits & 7u) << 12) | L;
-    const uint32_t w16 = ld(ib + (16u << 7));
-    const uint32_t w8 = ld(ib + (8u << 7)), w24 = ld(ib + (24u << 7));
-    REDUX_DEC_LEVEL((w16 & 0xFFFFu) + 16u)
-    const uint32_t x3 = left ? w8 : w24;
-    REDUX_DEC_LEVEL((x3 & 0xFFFFu) + 8u)
-    // round C: levels 2, 1, 0 under i = bits << 3.  The four dwords i/2 .. i/2+3 hold nodes
-    // (i, i+1), (i+2, i+3), (i+4, i+5), (i+6, i+7): all seven candidates.
-    ib                = ((bits & 31u) << 10) | L;
-    const uint32_t d0 = ld(ib), d1 = ld(ib + 256u), d2 = ld(ib + 512u), d3 = ld(ib + 768u);
-    REDUX_DEC_LEVEL((d2 & 0xFFFFu) + 4u) // node i+4
-    const uint32_t e1 = left ? d1 : d3;  // level 1: node i+2 or i+6 (low halves)
-    const uint32_t e0 = left ? d0 : d2;  // level 0 if level 1 goes left: node i+1 or i+5 (high halves)
-    REDUX_DEC_LEVEL((e1 & 0xFFFFu) + 2u)
-    const uint32_t x0 = left ? e0 : e1;  // ... if it goes right: node i+3 or i+7, the high half of level 1's dword
-    REDUX_DEC_LEVEL((x0 >> 16) + 1u)
-#undef REDUX_DEC_LEVEL
-    f.s  = bits & 0xFFu;
-    f.lo = v + q + 1u;  // v - rem
-    f.hi = v + hq + 1u; // upper boundary of the last level that went left
-    return f;
-}
 
 // The same descent under a STATIC model (redux_static.hpp): node i, i = 1..255, is the Fenwick form of the fixed
 // cumulative table -- cum[i] - cum[i - lowbit(i)], the total frequency of the symbols in [i - lowbit(i), i) -- as
@@ -404,24 +346,6 @@ __device__ __forceinline__ void dec_update_regs(DecTop &T, uint32_t s)
     T.n160 += (s - 128u) < 32u ? 1u : 0u;
     T.n224 += (s - 192u) < 32u ? 1u : 0u;
 }
-__device__ __forceinline__ void dec_update_lds(uint32_t *lds, const uint32_t (&A)[8], uint32_t s)
-{
-    const uint32_t ss = s << 7, ns = ~s;
-#pragma unroll
-    for (int b = 0; b < 5; b++) {
-        const uint32_t keep = b ? (((0xFFu << b) & 0xFFu) << 7) : (0xFEu << 7);
-        const uint32_t addr = (ss & keep) | A[b];
-        const uint32_t inc  = b ? ((ns >> b) & 1u) : ((ns & 1u) << 16);
-        __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + addr), inc, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-__device__ __forceinline__ void dec_update(uint32_t *lds, const uint32_t (&A)[8], DecTop &T, uint32_t s)
-{
-    dec_update_regs(T, s);
-    dec_update_lds(lds, A, s);
-}
-
 // value = floor(((V - low + 1) * count - 1) / range) (codec.rs:129-131) in f64.  Numerator nd (< 2^49) and range xd (an
 // integer in [1, 2^32]) are exact.  The raw v_rcp_f64 of gfx950 is within 2^-24 (measured: 2^-24.4) of 1/xd for EVERY
 // integer xd in [1, 2^32] (checked exhaustively on the device by redux_debug_rcp_check, tests/test_gpu_parity.py), and the
@@ -526,35 +450,25 @@ __device__ __forceinline__ void dec_commit_careful(DecLane &S, const DecFound &f
 // by the lanes) instead of 64 per-lane trees, nothing is updated, total frequency and reciprocal are constants.
 // Everything else -- code value, narrowing, renormalisation, bit reader, output staging, the careful per-lane
 // commit -- is the same code.
-// MODE 0: adaptive model; 1: static model, descent over the table's Fenwick form; 2: static model, direct lookup
-// (`lds` is then this wave's stream ring alone, `lut` / `ctab` the workgroup's shared tables, filled by the caller).
+// MODE 1: descent over the table's Fenwick form; 2: direct lookup (`lds` is then this wave's stream ring alone, `lut` /
+// `ctab` the workgroup's shared tables, filled by the caller).  (The adaptive model's decoder, which this body was
+// derived from, has its own tree layout and loop structure: redux_decode_adaptive.hpp.)
 template <bool CB32, int MODE>
 __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds, const uint32_t *cum, double rc_static,
                                                  uint32_t lane = threadIdx.x, uint64_t group = blockIdx.x,
                                                  const uint8_t *lut = nullptr, const uint32_t *ctab = nullptr)
 {
-    constexpr bool     STATIC      = MODE != 0;
-    constexpr uint32_t kModelBytes = MODE == 2 ? 0 : MODE == 1 ? kStaticTreeDwords * 4 : 128 * 64 * 4;
+    static_assert(MODE == 1 || MODE == 2, "static models only");
+    constexpr uint32_t kModelBytes = MODE == 2 ? 0 : kStaticTreeDwords * 4;
     const uint64_t blk  = group * 64 + lane;
     const bool     live = blk < a.nblocks;
 
-    if (MODE == 2) {
-        // (tables filled by the caller, which also synchronises)
-    } else if (STATIC) {
+    if (MODE == 1) { // (MODE 2: tables filled by the caller, which also synchronises)
         for (uint32_t i = lane; i < 256; i += 64)
             lds[dec_static_slot(i)] = i ? cum[i] - cum[i - (i & (0u - i))] : 0u;
-    } else {
-        for (uint32_t i = lane; i < 128 * 64 / 4; i += 64)
-            reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     const uint32_t L = lane * 4u;
-    uint32_t       A[8];
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        A[b] = (b ? (1u << (b + 7)) : 0u) | L;
-        asm volatile("" : "+v"(A[b]));
-    }
 
     const uint32_t cb = CB32 ? 32u : a.code_bits, sh = CB32 ? 0u : 32 - cb;
     uint64_t       size = 0;
@@ -567,8 +481,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     const uint32_t stream_bits = (uint32_t)(size * 8);
     uint8_t       *dst         = a.out + (live ? blk : 0) * (uint64_t)a.block_size;
     const uint32_t capn        = a.block_size;
-    const rc_ptr   rcp         = (rc_ptr)a.rc;
-    const uint32_t nfreeze     = a.nfreeze;
     const bool     aligned4    = a.aligned4 != 0;
     const bool     aligned16   = a.aligned4 == 2;
 
@@ -645,9 +557,9 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     if (MODE == 1)
         T = DecTop{lds[dec_static_slot(128)], lds[dec_static_slot(64)], lds[dec_static_slot(192)], lds[dec_static_slot(32)],
                    lds[dec_static_slot(96)], lds[dec_static_slot(160)], lds[dec_static_slot(224)]};
-    const uint32_t cum256  = STATIC ? cum[256] : 0u;
-    const uint32_t c_const = STATIC ? cum[257] : 0u; // total_frequency() of the static model
-#define REDUX_DEC_SEARCH(v_, c_) (MODE == 2 ? dec_search_lut(lut, ctab, v_, cum256) : MODE == 1 ? dec_search_static(lds, T, v_, cum256) : dec_search(lds, L, T, v_, c_))
+    const uint32_t cum256  = cum[256];
+    const uint32_t c_const = cum[257]; // total_frequency() of the static model
+#define REDUX_DEC_SEARCH(v_) (MODE == 2 ? dec_search_lut(lut, ctab, v_, cum256) : dec_search_static(lds, T, v_, cum256))
 
 #define REDUX_DEC_READER                                                                                               \
     {                                                                                                                  \
@@ -707,42 +619,17 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     }
 
     // ---------------- lock-step groups of four symbols ----------------
-    // While p < min(capacity, freeze point) every step updates the model and has room for its symbol.  A step is
-    // computed AND committed for all 64 lanes without predication; the only things that can end a block here -- the EOF
-    // symbol (codec.rs:136-138) and a stream that runs dry in the renormalisation (bitio/mod.rs:107) -- are terminal, so
-    // a lane they happen to records its result in a small exec-masked block and from then on computes on garbage that
-    // nobody reads (every address it forms stays inside its own tree column, ring column and stream buffer).
-    //
-    // A decoder wave is alone on its SIMD (the LDS holds four groups per CU), so nothing hides its two LDS round trips
-    // per step but its own instructions.  The step is therefore laid out by hand (sched_barrier pins the phases):
-    //   A  code value (codec.rs:129-131)
-    //   B  levels 7-5 of get_symbol from registers; the three candidate loads of levels 4, 3
-    //      | in their shadow: the register levels' share of update() -- it needs the top three bits of the symbol
-    //      | only -- and the bit reader's refill for this step
-    //   C  levels 4, 3; the four candidate loads of levels 2-0
-    //      | in their shadow: the update of the level-4 and level-3 nodes (their addresses are two of the three just
-    //      | loaded from), the narrowing's common factor
-    //   D  levels 2-0, narrowing, renormalisation in closed form
-    //   E  update of the level 2-0 nodes, new interval, new code value
-    const uint32_t pfast = STATIC ? capn : (capn < nfreeze ? capn : nfreeze);
+    // A step is computed AND committed for all 64 lanes without predication; the only things that can end a block here --
+    // the EOF symbol (codec.rs:136-138) and a stream that runs dry in the renormalisation (bitio/mod.rs:107) -- are
+    // terminal, so a lane they happen to records its result in a rarely entered block and from then on computes on
+    // garbage that nobody reads (every address it forms stays inside the tables, its ring column and its stream buffer).
+    // The phases of a step are fenced for the scheduler so that the bit reader's refill sits in the shadow of the
+    // search's second LDS round trip.
+    const uint32_t pfast = capn;
     uint32_t livemask = (int32_t)S.dflag < 0 ? 0x7FFFFFFFu : 0xFFFFFFFFu; // sign bit cleared once the block is finished
     uint32_t fin_obuf = 0, fin_cons = S.consumed;                         // what a lane that finishes in this loop ends with
     if (aligned4) {
-        double cdm1 = STATIC ? (double)(c_const - 1u) : 256.0, cd = STATIC ? (double)c_const : 257.0;
-        // The group's four reciprocals are loaded a group ahead with VECTOR loads (every lane the
-        // same 32 bytes), behind the ring's chunk request: their latency is covered by the one
-        // vmcnt wait of the next group.  A scalar load would share lgkmcnt with the LDS, return
-        // out of order and so sit in front of the next LDS wait wherever it is issued.
-        typedef double f64x4 __attribute__((ext_vector_type(4)));
-        typedef const __attribute__((address_space(1))) f64x4 *grc4;
-        const grc4 rcv = (grc4)(uintptr_t)a.rc; // 256-byte aligned workspace, p a multiple of 4
-        f64x4      rcg = STATIC ? f64x4{rc_static, rc_static, rc_static, rc_static} : rcv[0], rcn;
-        asm volatile("" : "+v"(rcg)); // arrived before the loop: no in-loop wait inherits this load
-        auto ld = [&](uint32_t byte) { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + byte); };
-        auto bump = [&](uint32_t byte, uint32_t inc) {
-            __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + byte), inc, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
+        const double cdm1 = (double)(c_const - 1u), cd = (double)c_const;
 #define REDUX_DEC_LEVEL(t)                                                                                             \
     left = __builtin_uadd_overflow(q, (t), &q2); /* carries exactly when the probe fails (rem < t: go left) */          \
     bits = __builtin_amdgcn_alignbit(bits, q2, 31);                                                                    \
@@ -754,21 +641,20 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
             REDUX_DEC_REQUEST
-            rcn = STATIC ? rcg : rcv[(p >> 2) + 1]; // the table has 32 entries of slack (geometry())
 #pragma unroll
             for (int K = 0; K < 4; K++) {
-                const double   rc = rcg[K];
-                const uint32_t c  = STATIC ? c_const : 257u + p + K;
+                const double   rc = rc_static;
+                const uint32_t c  = c_const;
                 // ---- A: code value
                 const uint32_t R1  = (~(S.ihigh + S.low)) >> sh;
                 const uint32_t Vd  = (S.W - S.low) >> sh;
                 const double   R1d = (double)R1;
                 const uint32_t v   = dec_value(R1d, Vd, cd, cdm1);
                 // ---- B: get_symbol, first round
-                uint32_t q = ~v, hq = q + (STATIC ? cum256 : c - 1u), bits = 0, q2;
+                uint32_t q = ~v, hq = q + cum256, bits = 0, q2;
                 uint32_t eofq = hq; // top bit set: v >= count - 1 -> the EOF symbol (adaptive_tree.rs:116)
-                bool     left, l4 = false, l2 = false, l1 = false;
-                uint32_t ibB = 0, ibC = 0, a3 = 0, sym = 0;
+                bool     left;
+                uint32_t sym = 0;
                 uint32_t w16 = 0, w8 = 0, w24 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, n5 = 0, n6 = 0, n7 = 0;
                 if constexpr (MODE == 2) {
                     eofq = cum256 - 1u - v;
@@ -779,32 +665,8 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                     REDUX_DEC_LEVEL(x6)
                     const uint32_t x5 = left ? c5l : c5r;
                     REDUX_DEC_LEVEL(x5)
-                    if constexpr (MODE == 0) {
-                        ibB = (bits << 12) | L; // prefix i = bits << 5: nodes i+16; i+8, i+24 (three dwords)
-                        w16 = ld(ibB + (16u << 7));
-                        w8  = ld(ibB + (8u << 7));
-                        w24 = ld(ibB + (24u << 7));
-                    } else {
-                        const uint32_t *r = lds + bits * 33u; // prefix i = bits << 5 at dword i + (i >> 5)
-                        w16 = r[16]; w8 = r[8]; w24 = r[24];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // ---- B's shadow (1): update(s+1), adaptive_tree.rs:83-92, for the levels kept in registers: node e
-                    // of level b is incremented iff s is in [e - 2^b, e), which the top three bits of s decide.
-                    // (The copy of the bits made opaque HERE and the pin below keep this block between the loads and
-                    // their first use: the compiler would otherwise sink it to the next step, where the values are used.)
-                    if constexpr (MODE == 0) {
-                        uint32_t b3 = bits; // s >> 5
-                        asm volatile("" : "+v"(b3));
-                        T.n128 += b3 < 4u ? 1u : 0u;
-                        T.n64 += b3 < 2u ? 1u : 0u;
-                        T.n192 += (b3 - 4u) < 2u ? 1u : 0u;
-                        T.n32 += b3 == 0u ? 1u : 0u;
-                        T.n96 += b3 == 2u ? 1u : 0u;
-                        T.n160 += b3 == 4u ? 1u : 0u;
-                        T.n224 += b3 == 6u ? 1u : 0u;
-                        asm volatile("" : "+v"(T.n128), "+v"(T.n64), "+v"(T.n192), "+v"(T.n32), "+v"(T.n96), "+v"(T.n160), "+v"(T.n224));
-                    }
+                    const uint32_t *r = lds + bits * 33u; // prefix i = bits << 5 at dword i + (i >> 5)
+                    w16 = r[16]; w8 = r[8]; w24 = r[24];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- C: second round
@@ -812,16 +674,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                 if constexpr (MODE == 2) {
                     lo = ctab[sym];
                     hi = ctab[sym + 1u];
-                } else if constexpr (MODE == 0) {
-                    REDUX_DEC_LEVEL((w16 & 0xFFFFu) + 16u)
-                    l4 = left;
-                    const uint32_t x3 = left ? w8 : w24;
-                    a3 = ibB + (left ? (8u << 7) : (24u << 7));
-                    REDUX_DEC_LEVEL((x3 & 0xFFFFu) + 8u)
-                    // levels 2, 1, 0 under i = bits << 3.  The four dwords i/2 .. i/2+3 hold nodes
-                    // (i, i+1), (i+2, i+3), (i+4, i+5), (i+6, i+7): all seven candidates.
-                    ibC = (bits << 10) | L;
-                    d0 = ld(ibC); d1 = ld(ibC + 256u); d2 = ld(ibC + 512u); d3 = ld(ibC + 768u);
                 } else {
                     REDUX_DEC_LEVEL(w16)
                     const uint32_t x3 = left ? w8 : w24;
@@ -830,34 +682,15 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                     d0 = r4[1]; d1 = r4[2]; d2 = r4[3]; d3 = r4[4]; n5 = r4[5]; n6 = r4[6]; n7 = r4[7];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // ---- C's shadow: the level-4 and level-3 nodes' update (addresses: two of round B's three), the factor
-                // both ends of the new interval share (codec.rs:133-134)
-                if constexpr (MODE == 0) {
-                    bump(ibB + (16u << 7), l4 ? 1u : 0u);
-                    bump(a3, (bits & 1u) ^ 1u);
-                }
-                // ... and the bit reader's refill for this step (bitio/mod.rs:78-120)
+                // ---- C's shadow: the bit reader's refill for this step (bitio/mod.rs:78-120), the factor both ends of the
+                // new interval share (codec.rs:133-134)
                 asm volatile("" : "+v"(S.bcnt));
                 REDUX_DEC_READER
                 double Y = __builtin_fma(R1d, rc, rc);
-                if (!STATIC) {
-                    cdm1 = cd;
-                    cd += 1.0;
-                    asm volatile("" : "+v"(Y), "+v"(cd), "+v"(S.bbits), "+v"(S.bcnt));
-                } else
-                    asm volatile("" : "+v"(Y), "+v"(S.bbits), "+v"(S.bcnt));
+                asm volatile("" : "+v"(Y), "+v"(S.bbits), "+v"(S.bcnt));
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- D: last round, narrowing + renormalisation (codec.rs:133-161)
-                if constexpr (MODE == 0) {
-                    REDUX_DEC_LEVEL((d2 & 0xFFFFu) + 4u) // node i+4
-                    l2 = left;
-                    const uint32_t e1 = left ? d1 : d3;  // level 1: node i+2 or i+6 (low halves)
-                    const uint32_t e0 = left ? d0 : d2;  // level 0 if level 1 goes left: node i+1 or i+5 (high halves)
-                    REDUX_DEC_LEVEL((e1 & 0xFFFFu) + 2u)
-                    l1 = left;
-                    const uint32_t x0 = left ? e0 : e1;  // ... if it goes right: node i+3 or i+7, the high half of level 1's dword
-                    REDUX_DEC_LEVEL((x0 >> 16) + 1u)
-                } else if constexpr (MODE == 1) {
+                if constexpr (MODE == 1) {
                     REDUX_DEC_LEVEL(d3)                  // node i+4
                     const uint32_t e1  = left ? d1 : n6; // level 1: node i+2 or i+6
                     const uint32_t e0l = left ? d0 : n5, e0r = left ? d2 : n7; // level 0: i+1 / i+5 or i+3 / i+7
@@ -884,11 +717,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                 const uint32_t cons0 = S.consumed, cons2 = cons0 + n;
                 const uint32_t e     = (eofq | (stream_bits - cons2)) & livemask;
                 // ---- E: commit, every lane
-                if constexpr (MODE == 0) {
-                    bump(ibC + 512u, l2 ? 1u : 0u);                                   // node i+4
-                    bump(ibC + 256u + (l2 ? 0u : 512u), l1 ? 1u : 0u);                // node i+2 or i+6
-                    bump(ibC + ((sym & 6u) << 7), ((sym & 1u) ^ 1u) << 16);           // node s|1: high half of dword s >> 1
-                }
                 S.low      = (low2 << j) & 0x7FFFFFFFu;
                 S.ihigh    = (ih2 << j) & 0x7FFFFFFFu;
                 S.consumed = cons2;
@@ -915,7 +743,6 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                     livemask = fin ? 0x7FFFFFFFu : livemask;
                 }
             }
-            rcg = rcn;
         }
 #undef REDUX_DEC_LEVEL
     }
@@ -927,9 +754,8 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     for (;; p++) {
         if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
             break;
-        const uint32_t nup = p < nfreeze ? p : nfreeze;
-        const double   rc  = STATIC ? rc_static : rcp[nup];
-        const uint32_t c   = STATIC ? c_const : 257u + nup;
+        const double   rc  = rc_static;
+        const uint32_t c   = c_const;
         if ((p & 3) == 0) {
             REDUX_DEC_RETIRE
             REDUX_DEC_STORE
@@ -940,9 +766,8 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
         const uint32_t Vd  = (S.W - S.low) >> sh;
         const double   R1d = (double)R1;
         const uint32_t v   = dec_value(R1d, Vd, (double)c, (double)(c - 1u));
-        const DecFound f   = REDUX_DEC_SEARCH(v, c);
-        dec_commit_careful<CB32>(S, f, R1, R1d, rc, c, sh, stream_bits, p, p < capn, aligned4, dst,
-                                 [&](uint32_t s) { if (!STATIC && p < nfreeze) dec_update(lds, A, T, s); });
+        const DecFound f   = REDUX_DEC_SEARCH(v);
+        dec_commit_careful<CB32>(S, f, R1, R1d, rc, c, sh, stream_bits, p, p < capn, aligned4, dst, [](uint32_t) {});
     }
 #undef REDUX_DEC_READER
 #undef REDUX_DEC_RETIRE
