@@ -103,6 +103,38 @@ int redux_decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t
                         uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes,
                         int32_t *block_status);
 
+/* ---- many independent inputs in one call ("_v": a vector of inputs) ----------------------
+ * The reference's harness codes every file by itself, one redux::compress / decompress per file
+ * (tests/corpora.rs:32-85).  These calls do that for `ninputs` inputs at once: input i is the
+ * bytes in[in_off[i] .. in_off[i] + in_len[i]) and is cut into blocks of block_size ON ITS OWN
+ * (its last block may be shorter; an empty input is one empty block), so every block's stream
+ * equals the one redux_encode_blocks produces when it is called for that input alone.  Blocks
+ * are numbered input by input: input i owns blocks first(i) .. first(i) + redux_block_count(
+ * in_len[i], block_size) - 1, first(0) = 0.  One launch codes all of them.
+ *
+ * redux_block_count_v   total number of blocks.
+ * redux_block_table_v   the block table of these inputs in LAUNCH order: whole blocks first,
+ *                       then the shorter ones by decreasing length, so that the 64 lanes of a
+ *                       wave have the same amount of work; entry.index = the block's number.
+ *                       `table` may be NULL (count only).  Returns the number of blocks.
+ * redux_encode_blocks_v out / out_offsets (total blocks + 1) / block_status (may be NULL) as in
+ *                       redux_encode_blocks, in block-number order.
+ * redux_decode_blocks_v the inverse: in / in_offsets as produced above; input i's blocks are
+ *                       written to out[out_off[i] ..) back to back, at most out_len[i] bytes
+ *                       (a block of input i may hold min(block_size, what is left of out_len[i]));
+ *                       out_sizes / block_status per block.
+ * Device path: symbol_bits == 8 and code_bits <= 32 (other valid triples: REDUX_UNSUPPORTED from
+ * these calls only -- call redux_encode_blocks per input instead). */
+uint64_t redux_block_count_v(const uint64_t *in_len, uint64_t ninputs, uint32_t block_size);
+uint64_t redux_block_table_v(const uint64_t *in_off, const uint64_t *in_len, uint64_t ninputs, uint32_t block_size,
+                             redux_block *table);
+int redux_encode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
+                          uint64_t ninputs, uint32_t block_size, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets,
+                          int32_t *block_status);
+int redux_decode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint8_t *out,
+                          const uint64_t *out_off, const uint64_t *out_len, uint64_t ninputs, uint32_t block_size,
+                          uint32_t *out_sizes, int32_t *block_status);
+
 /* Whole-stream drop-ins for redux::compress / redux::decompress (src/lib.rs:102,113): the
  * input is ONE block of any length, so the stream equals the reference's for the same bytes.
  * One coder = one GPU lane: correct but serial; the block API is the accelerated path.
@@ -136,6 +168,25 @@ int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void 
                             uint64_t nblocks, uint32_t block_size, void *d_out, uint64_t out_cap,
                             void *d_out_sizes /* u32[nblocks] */, void *d_block_status, void *d_summary,
                             void *d_workspace, uint64_t workspace_bytes, void *stream);
+
+/* The `_v` calls with everything in device memory.  d_table: redux_block[nblocks] in launch order
+ * (redux_block_table_v builds one; any order is valid, a wave's 64 consecutive entries run in
+ * lock-step for as long as its shortest block lasts).  Encode: entry.offset is the block's first
+ * byte in d_in (in_bytes = size of that buffer, below 4 GiB), entry.length its size.  Decode:
+ * entry.offset is where the block's output starts in d_out (out_bytes = size of that buffer),
+ * entry.length the room it has there.  flags: REDUX_V_ALIGNED16 promises that d_in / d_out and
+ * every entry.offset are multiples of 16 (the fast kernels need it; without it the call is
+ * correct and slow).  Workspace: redux_encode_workspace_bytes(p, nblocks * block_size, block_size)
+ * / redux_decode_workspace_bytes(p, nblocks, block_size). */
+enum { REDUX_V_ALIGNED16 = 1 };
+int redux_encode_blocks_v_dev(const redux_params *p, const void *d_in, uint64_t in_bytes, const void *d_table,
+                              uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out, uint64_t out_cap,
+                              void *d_out_offsets, void *d_block_status, void *d_summary, void *d_workspace,
+                              uint64_t workspace_bytes, void *stream);
+int redux_decode_blocks_v_dev(const redux_params *p, const void *d_in, const void *d_in_offsets, const void *d_table,
+                              uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out, uint64_t out_bytes,
+                              void *d_out_sizes, void *d_block_status, void *d_summary, void *d_workspace,
+                              uint64_t workspace_bytes, void *stream);
 
 /* The two phases of redux_encode_blocks_dev, exposed so a harness can time the coder kernel
  * by itself: (1) code every block into its padded slot inside the workspace and record the

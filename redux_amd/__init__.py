@@ -7,6 +7,6 @@ here computes a bitstream on the CPU.
 from .api import (  # noqa: F401
     Error, Eof, InvalidInput, IoError, OutputTooSmall, Unsupported,
     Parameters, AdaptiveTreeModel,
-    compress, decompress, compress_blocks, decompress_blocks,
+    compress, decompress, compress_blocks, decompress_blocks, compress_blocks_v, decompress_blocks_v, block_table_v,
     DeviceEncoder, DeviceDecoder, DeviceStaticCoder, gen_iid, gen_zipf, zipf_thresholds, version,
 )

@@ -176,6 +176,77 @@ def decompress_blocks(streams, offsets, block_size, params=(8, 30, 32), check=Tr
     return out, sizes, status
 
 
+# ---- many independent inputs in one call (tests/corpora.rs:32-85 codes file by file) --------
+BLOCK_DTYPE = np.dtype([("offset", "<u8"), ("length", "<u4"), ("index", "<u4")])  # redux_block
+
+
+def block_table_v(offsets, lengths, block_size):
+    """redux_block_table_v: the block table (launch order) of inputs at `offsets` with `lengths`."""
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+    L = _lib.lib()
+    nb = L.redux_block_count_v(ln.ctypes.data, len(ln), block_size)
+    tab = np.zeros(nb, dtype=BLOCK_DTYPE)
+    L.redux_block_table_v(off.ctypes.data, ln.ctypes.data, len(ln), block_size, tab.ctypes.data)
+    return tab
+
+
+def compress_blocks_v(inputs, block_size, params=(8, 30, 32)):
+    """redux::compress of every block of every input (a list of bytes-like objects), ONE launch for all of
+    them; each input is cut into blocks on its own.  Returns (dense streams uint8, offsets
+    uint64[nblocks+1], status int32[nblocks], first_block int64[len(inputs)+1]): input i owns blocks
+    first_block[i] .. first_block[i+1]-1."""
+    P = _params_of(params)
+    L = _lib.lib()
+    cp = P._c()
+    _raise(L.redux_device_supports(C.byref(cp)))
+    if block_size <= 0 or len(inputs) == 0:
+        raise InvalidInput()
+    arrs = [_u8(x) for x in inputs]
+    lens = np.array([len(a) for a in arrs], dtype=np.uint64)
+    offs_in = np.zeros(len(arrs), dtype=np.uint64)
+    offs_in[1:] = np.cumsum(lens)[:-1]
+    flat = np.concatenate(arrs) if int(lens.sum()) else np.zeros(0, dtype=np.uint8)
+    counts = np.array([L.redux_block_count(int(n), block_size) for n in lens], dtype=np.int64)
+    first = np.zeros(len(arrs) + 1, dtype=np.int64)
+    first[1:] = np.cumsum(counts)
+    nb = int(first[-1])
+    cap = nb * L.redux_encode_slot_bytes(C.byref(cp), block_size)
+    out = np.empty(cap, dtype=np.uint8)
+    offs = np.zeros(nb + 1, dtype=np.uint64)
+    status = np.zeros(nb, dtype=np.int32)
+    _raise(L.redux_encode_blocks_v(C.byref(cp), _ptr(flat), offs_in.ctypes.data, lens.ctypes.data, len(arrs), block_size,
+                                   out.ctypes.data, cap, offs.ctypes.data, status.ctypes.data))
+    return out[: int(offs[-1])], offs, status, first
+
+
+def decompress_blocks_v(streams, offsets, lengths, block_size, params=(8, 30, 32), check=True):
+    """The inverse of compress_blocks_v: `lengths[i]` is the decoded size of input i.  Returns (list of
+    uint8 arrays, sizes uint32[nblocks], status int32[nblocks])."""
+    P = _params_of(params)
+    L = _lib.lib()
+    cp = P._c()
+    _raise(L.redux_device_supports(C.byref(cp)))
+    a = _u8(streams)
+    offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lens = np.ascontiguousarray(lengths, dtype=np.uint64)
+    if block_size <= 0 or len(lens) == 0:
+        raise InvalidInput()
+    nb = L.redux_block_count_v(lens.ctypes.data, len(lens), block_size)
+    if nb != len(offs) - 1:
+        raise InvalidInput()
+    out_off = np.zeros(len(lens), dtype=np.uint64)
+    out_off[1:] = np.cumsum(lens)[:-1]
+    out = np.zeros(max(1, int(lens.sum())), dtype=np.uint8)
+    sizes = np.zeros(nb, dtype=np.uint32)
+    status = np.zeros(nb, dtype=np.int32)
+    st = L.redux_decode_blocks_v(C.byref(cp), _ptr(a), offs.ctypes.data, out.ctypes.data, out_off.ctypes.data, lens.ctypes.data,
+                                 len(lens), block_size, sizes.ctypes.data, status.ctypes.data)
+    if check:
+        _raise(st)
+    return [out[int(o): int(o) + int(n)] for o, n in zip(out_off, lens)], sizes, status
+
+
 # ---- src/lib.rs:102-120: whole-stream drop-ins --------------------------------------------
 def compress(istream, ostream, model):
     """redux::compress(istream, ostream, model) -> (bytes_in, bytes_out).  The whole input is

@@ -95,8 +95,16 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
     __shared__ uint32_t lds[Tree<U16>::kDwords];
     constexpr int  KS   = Tree<U16>::kShift;
     const uint32_t lane = threadIdx.x;
-    const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
-    const bool     live = blk < a.nblocks;
+    const uint64_t slot = (uint64_t)blockIdx.x * 64 + lane;
+    const bool     live = slot < a.nblocks;
+    uint64_t       blk = slot, dst_off = slot * (uint64_t)a.block_size;
+    uint32_t       capn = a.block_size;
+    if (a.table && live) { // block table: see DecArgs
+        const redux_block e = a.table[slot];
+        blk     = e.index;
+        dst_off = e.offset;
+        capn    = e.length;
+    }
 
     for (uint32_t i = lane; i < Tree<U16>::kDwords / 4; i += 64)
         reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
@@ -113,8 +121,7 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
         sp                = a.in + o0;
     }
     const uint64_t stream_bits = size * 8;
-    uint8_t       *dst         = a.out + (live ? blk : 0) * (uint64_t)a.block_size;
-    const uint32_t capn        = a.block_size;
+    uint8_t       *dst         = a.out + (live ? dst_off : 0);
     const rc_ptr   rcp         = (rc_ptr)a.rc;
 
     BitIn B;

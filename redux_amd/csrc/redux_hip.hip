@@ -26,11 +26,13 @@
 #include "../../include/redux_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 namespace redux {
 
@@ -380,15 +382,19 @@ uint64_t redux_encode_workspace_bytes(const redux_params *p, uint64_t in_len, ui
     return geometry(p, in_len, block_size).total;
 }
 
-int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size,
-                           void *d_block_status, void *d_workspace, uint64_t workspace_bytes, void *stream)
+// d_table != null: the block table of redux_encode_blocks_v_dev (tbl_blocks entries; in_len = bytes of d_in)
+static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size,
+                             const redux_block *d_table, uint64_t tbl_blocks, bool tbl_aligned16, void *d_block_status,
+                             void *d_workspace, uint64_t workspace_bytes, void *stream)
 {
     int st = check_params(p);
     if (st != REDUX_OK)
         return st;
     if (block_size == 0 || !d_workspace || !d_block_status || (in_len && !d_in))
         return REDUX_INVALID_INPUT;
-    const Geometry g = geometry(p, in_len, block_size);
+    const Geometry g = d_table ? geometry(p, tbl_blocks * (uint64_t)block_size, block_size) : geometry(p, in_len, block_size);
+    if (d_table && (g.gen || g.any || in_len > 0xFFFFFFFFull || tbl_blocks == 0)) // lane offsets into d_in are 32-bit
+        return tbl_blocks == 0 ? REDUX_INVALID_INPUT : REDUX_UNSUPPORTED;
     if (workspace_bytes < g.total)
         return REDUX_OUTPUT_TOO_SMALL;
     if (((uintptr_t)d_workspace) & 255)
@@ -457,9 +463,9 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     a.slot_cap   = g.slot_cap;
     a.nfreeze    = g.nfreeze;
     a.code_bits  = p->code_bits;
-    a.aligned16  = ((((uintptr_t)d_in) & 15) == 0 && (block_size & 15) == 0) ? 1 : 0;
+    a.aligned16  = ((((uintptr_t)d_in) & 15) == 0 && (d_table ? tbl_aligned16 : (block_size & 15) == 0)) ? 1 : 0;
     a.claims     = (uint32_t *)(ws + g.off_mode + 256);
-    a.table      = nullptr;
+    a.table      = d_table;
     // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset;
     // otherwise (giant blocks, whole-stream mode) one block per wave.
     a.lanes = encode_lanes(g, block_size);
@@ -483,9 +489,16 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
     return REDUX_OK;
 }
 
+int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size,
+                           void *d_block_status, void *d_workspace, uint64_t workspace_bytes, void *stream)
+{
+    return encode_slots_impl(p, d_in, in_len, block_size, nullptr, 0, false, d_block_status, d_workspace, workspace_bytes, stream);
+}
+
 // scan + gather of the slots a coder kernel left in the workspace laid out by g
 static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *d_out_offsets, void *d_block_status,
-                        void *d_summary, void *d_workspace, uint64_t workspace_bytes, void *stream)
+                        void *d_summary, void *d_workspace, uint64_t workspace_bytes, void *stream,
+                        const redux_block *d_table = nullptr)
 {
     if (!d_workspace || !d_block_status || !d_out_offsets || !d_out)
         return REDUX_INVALID_INPUT;
@@ -516,7 +529,7 @@ static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *
     ca.nblocks    = g.nblocks;
     ca.mode       = (const uint32_t *)(ws + g.off_mode);
     ca.cap_rows   = (uint32_t)(g.slot_bytes / 4);
-    ca.table      = nullptr;
+    ca.table      = d_table;
     k_compact<<<(uint32_t)g.nblocks, 256, 0, s>>>(ca);
 #if REDUX_ROWS // the mode word decides on the device which of the two does the work
     if (!g.any && g.u16) {
@@ -551,6 +564,75 @@ int redux_encode_blocks_dev(const redux_params *p, const void *d_in, uint64_t in
         return st;
     return redux_compact_slots_dev(p, in_len, block_size, d_out, out_cap, d_out_offsets, d_block_status, d_summary,
                                    d_workspace, workspace_bytes, stream);
+}
+
+int redux_encode_blocks_v_dev(const redux_params *p, const void *d_in, uint64_t in_bytes, const void *d_table,
+                              uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out, uint64_t out_cap,
+                              void *d_out_offsets, void *d_block_status, void *d_summary, void *d_workspace,
+                              uint64_t workspace_bytes, void *stream)
+{
+    if (!d_table)
+        return REDUX_INVALID_INPUT;
+    int st = encode_slots_impl(p, d_in, in_bytes, block_size, (const redux_block *)d_table, nblocks,
+                               (flags & REDUX_V_ALIGNED16) != 0, d_block_status, d_workspace, workspace_bytes, stream);
+    if (st != REDUX_OK)
+        return st;
+    return compact_with(geometry(p, nblocks * (uint64_t)block_size, block_size), d_out, out_cap, d_out_offsets, d_block_status,
+                        d_summary, d_workspace, workspace_bytes, stream, (const redux_block *)d_table);
+}
+
+uint64_t redux_block_count_v(const uint64_t *in_len, uint64_t ninputs, uint32_t block_size)
+{
+    if (block_size == 0 || (ninputs && !in_len))
+        return 0;
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < ninputs; i++)
+        n += redux_block_count(in_len[i], block_size);
+    return n;
+}
+
+uint64_t redux_block_table_v(const uint64_t *in_off, const uint64_t *in_len, uint64_t ninputs, uint32_t block_size,
+                             redux_block *table)
+{
+    const uint64_t nb = redux_block_count_v(in_len, ninputs, block_size);
+    if (!table || nb == 0 || nb > 0xFFFFFFFFull || !in_off)
+        return nb;
+    // whole blocks first, in block order; then the short ones (at most one per input), longest first
+    std::vector<redux_block> tails;
+    uint64_t k = 0, b = 0;
+    for (uint64_t i = 0; i < ninputs; i++) {
+        const uint64_t cnt = redux_block_count(in_len[i], block_size);
+        for (uint64_t j = 0; j < cnt; j++, b++) {
+            const uint64_t o   = j * (uint64_t)block_size;
+            const uint64_t rem = in_len[i] - o;
+            redux_block    e;
+            e.offset = in_off[i] + o;
+            e.length = rem < block_size ? (uint32_t)rem : block_size;
+            e.index  = (uint32_t)b;
+            if (e.length == block_size)
+                table[k++] = e;
+            else
+                tails.push_back(e);
+        }
+    }
+    std::stable_sort(tails.begin(), tails.end(), [](const redux_block &x, const redux_block &y) { return x.length > y.length; });
+    for (const redux_block &e : tails)
+        table[k++] = e;
+    return nb;
+}
+
+int redux_encode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
+                          uint64_t ninputs, uint32_t block_size, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets,
+                          int32_t *block_status)
+{
+    int st = check_params(p);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0 || ninputs == 0 || !in_off || !in_len || !out || !out_offsets)
+        return REDUX_INVALID_INPUT;
+    if (is_any(p))
+        return REDUX_UNSUPPORTED;
+    return host::encode_blocks_v(p, in, in_off, in_len, ninputs, block_size, out, out_cap, out_offsets, block_status);
 }
 
 int redux_encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_len, uint32_t block_size,
@@ -598,7 +680,8 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
 static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const void *d_in_offsets, uint64_t nblocks,
                                   uint32_t block_size, void *d_out, uint64_t out_cap, void *d_out_sizes,
                                   void *d_block_status, void *d_summary, void *d_workspace,
-                                  uint64_t workspace_bytes, void *stream, void *d_in_used)
+                                  uint64_t workspace_bytes, void *stream, void *d_in_used,
+                                  const redux_block *d_table = nullptr, bool tbl_aligned16 = false)
 {
     int st = check_params(p);
     if (st != REDUX_OK)
@@ -607,11 +690,13 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         return REDUX_INVALID_INPUT;
     if (nblocks == 0)
         return REDUX_OK;
-    if (out_cap < nblocks * (uint64_t)block_size)
+    if (!d_table && out_cap < nblocks * (uint64_t)block_size)
         return REDUX_OUTPUT_TOO_SMALL;
     const Geometry g = geometry(p, block_size, block_size);
     if (workspace_bytes < redux_decode_workspace_bytes(p, nblocks, block_size))
         return REDUX_OUTPUT_TOO_SMALL;
+    if (d_table && (g.gen || g.any))
+        return REDUX_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (g.gen) {
         GenDecArgs ga;
@@ -674,8 +759,10 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     a.aligned4   = ((((uintptr_t)d_out) & 3) == 0 && (block_size & 3) == 0) ? 1 : 0;
     if (a.aligned4 && (((uintptr_t)d_out) & 15) == 0 && (block_size & 15) == 0)
         a.aligned4 = 2; // 16-byte aligned blocks: the lock-step decoder stages four dwords per store
+    if (d_table) // where a block starts is the table's business: all of them 16-byte aligned, or nothing is assumed
+        a.aligned4 = (tbl_aligned16 && (((uintptr_t)d_out) & 15) == 0) ? 2 : 0;
     a.in_used    = (uint64_t *)d_in_used;
-    a.table      = nullptr;
+    a.table      = d_table;
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
     switch (pick_decode_kernel(g, p)) {
     case DecKernel::LockCb32: k_decode_lock<true><<<grid, 64, 0, s>>>(a); break;
@@ -727,6 +814,33 @@ int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void 
 {
     return decode_blocks_dev_impl(p, d_in, d_in_offsets, nblocks, block_size, d_out, out_cap, d_out_sizes,
                                   d_block_status, d_summary, d_workspace, workspace_bytes, stream, nullptr);
+}
+
+int redux_decode_blocks_v_dev(const redux_params *p, const void *d_in, const void *d_in_offsets, const void *d_table,
+                              uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out, uint64_t out_bytes,
+                              void *d_out_sizes, void *d_block_status, void *d_summary, void *d_workspace,
+                              uint64_t workspace_bytes, void *stream)
+{
+    if (!d_table || (nblocks && !d_out))
+        return REDUX_INVALID_INPUT;
+    return decode_blocks_dev_impl(p, d_in, d_in_offsets, nblocks, block_size, d_out, out_bytes, d_out_sizes, d_block_status,
+                                  d_summary, d_workspace, workspace_bytes, stream, nullptr, (const redux_block *)d_table,
+                                  (flags & REDUX_V_ALIGNED16) != 0);
+}
+
+int redux_decode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint8_t *out,
+                          const uint64_t *out_off, const uint64_t *out_len, uint64_t ninputs, uint32_t block_size,
+                          uint32_t *out_sizes, int32_t *block_status)
+{
+    int st = check_params(p);
+    if (st != REDUX_OK)
+        return st;
+    if (block_size == 0 || ninputs == 0 || !in_offsets || !out_off || !out_len || !out_sizes)
+        return REDUX_INVALID_INPUT;
+    if (is_any(p))
+        return REDUX_UNSUPPORTED;
+    return host::decode_blocks_v(p, in, in_offsets, out, out_off, out_len, ninputs, block_size, out_sizes, block_status,
+                                 decode_blocks_dev_impl);
 }
 
 static int decode_blocks_host(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,

@@ -131,8 +131,8 @@ struct Buf {
 };
 
 struct Slot {          // one chunk in flight
-    Buf d_in, d_ws, d_out, d_off, d_sz, d_st, d_sum, d_used; // device
-    Buf h_off, h_sz, h_st, h_sum, h_used;                    // pinned mirrors of the small arrays
+    Buf d_in, d_ws, d_out, d_off, d_sz, d_st, d_sum, d_used, d_tab; // device
+    Buf h_off, h_sz, h_st, h_sum, h_used, h_tab;                    // pinned mirrors of the small arrays
     hipEvent_t done = nullptr;                               // recorded after the chunk's kernels and small D2H copies
 };
 
@@ -250,8 +250,9 @@ static int ctx_release_all()
             if (c.stream[i]) (void)hipStreamSynchronize(c.stream[i]);
         for (Slot &s : c.slot) {
             free_buf_dev(s.d_in); free_buf_dev(s.d_ws); free_buf_dev(s.d_out); free_buf_dev(s.d_off); free_buf_dev(s.d_sz);
-            free_buf_dev(s.d_st); free_buf_dev(s.d_sum); free_buf_dev(s.d_used);
+            free_buf_dev(s.d_st); free_buf_dev(s.d_sum); free_buf_dev(s.d_used); free_buf_dev(s.d_tab);
             free_buf_pin(s.h_off); free_buf_pin(s.h_sz); free_buf_pin(s.h_st); free_buf_pin(s.h_sum); free_buf_pin(s.h_used);
+            free_buf_pin(s.h_tab);
             if (s.done) (void)hipEventDestroy(s.done);
             s.done = nullptr;
         }
@@ -461,11 +462,13 @@ static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_l
 // ================================================================================================
 // decode
 // ================================================================================================
+// decode_blocks_dev_impl of redux_hip.hip (defined after this header is included)
+typedef int (*DecodeDevCall)(const redux_params *, const void *, const void *, uint64_t, uint32_t, void *, uint64_t, void *, void *,
+                             void *, void *, uint64_t, void *, void *, const redux_block *, bool);
+
 static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
                          uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes, int32_t *block_status,
-                         uint64_t *in_used, int (*dev_call)(const redux_params *, const void *, const void *, uint64_t, uint32_t,
-                                                            void *, uint64_t, void *, void *, void *, void *, uint64_t, void *,
-                                                            void *))
+                         uint64_t *in_used, DecodeDevCall dev_call)
 {
     Ctx *cp = nullptr;
     int  rc = ctx_of_current_device(&cp);
@@ -581,7 +584,7 @@ static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_
                 HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
                 uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
                 r = dev_call(p, s.d_in.p, s.d_off.p, nb, block_size, s.d_out.p, nb * (uint64_t)block_size, s.d_sz.p, s.d_st.p,
-                             s.d_sum.p, ws, wsb, st, in_used ? s.d_used.p : nullptr);
+                             s.d_sum.p, ws, wsb, st, in_used ? s.d_used.p : nullptr, nullptr, false);
                 if (r != REDUX_OK)
                     return r;
                 HOST_TRY(hipEventRecord(s.done, st)); // (small result arrays: fetched by the drain thread, see encode_blocks)
@@ -605,6 +608,181 @@ static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_
     (void)out_cap;
     if (H.error != REDUX_OK)
         return H.error;
+    return first_bad;
+}
+
+// ================================================================================================
+// many independent inputs in one call (redux_encode_blocks_v / redux_decode_blocks_v)
+//
+// Consecutive inputs are packed into GROUPS of at most kVGroupBytes; a group is staged into HBM with every input at a
+// 16-byte boundary (so that the fast kernels apply), coded by ONE launch over its block table and copied back.  Groups
+// run one after the other on the context's first slot: the point of these calls is many small inputs -- the reference's
+// corpus harness, 36 files of 4 KB - 4 MB -- where what counts is that all blocks share a launch, not the overlap of
+// transfers with kernels that the chunk pipeline above gives gigabyte inputs.
+// ================================================================================================
+constexpr uint64_t kVGroupBytes = 512ull << 20;
+
+static int encode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len, uint64_t ninputs,
+                           uint32_t block_size, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
+{
+    Ctx *cp = nullptr;
+    int  rc = ctx_of_current_device(&cp);
+    if (rc != REDUX_OK)
+        return rc;
+    Ctx &c = *cp;
+    std::lock_guard<std::mutex> lock(c.mu);
+    if ((rc = ctx_init_locked(c)) != REDUX_OK)
+        return rc;
+    Slot       &s  = c.slot[0];
+    hipStream_t st = c.stream[0];
+    CopyPool    pool(kCopyThreads - 1);
+    uint64_t    piece_no = 0, blk_base = 0, out_base = 0;
+    int         first_bad = REDUX_OK;
+    std::vector<uint64_t>    doff;
+    std::vector<redux_block> tbl;
+    for (uint64_t i0 = 0; i0 < ninputs;) {
+        uint64_t i1 = i0, pos = 0;
+        doff.clear();
+        do {
+            doff.push_back(pos);
+            pos += (in_len[i1] + 15) & ~15ull;
+            i1++;
+        } while (i1 < ninputs && pos + in_len[i1] <= kVGroupBytes);
+        if (pos > 0xFFFFFFFFull) // (one input of 4 GiB or more: lane offsets are 32-bit; redux_encode_blocks takes it)
+            return REDUX_UNSUPPORTED;
+        const uint64_t nb = redux_block_count_v(in_len + i0, i1 - i0, block_size);
+        tbl.resize(nb);
+        redux_block_table_v(doff.data(), in_len + i0, i1 - i0, block_size, tbl.data());
+        const uint64_t ws_bytes = redux_encode_workspace_bytes(p, nb * (uint64_t)block_size, block_size);
+        const uint64_t bound    = nb * redux_encode_slot_bytes(p, block_size);
+        if ((rc = grow_dev(c, s.d_in, pos + 16)) || (rc = grow_dev(c, s.d_ws, ws_bytes + 256)) || (rc = grow_dev(c, s.d_out, bound + 16)) ||
+            (rc = grow_dev(c, s.d_off, (nb + 1) * 8)) || (rc = grow_dev(c, s.d_st, nb * 4)) || (rc = grow_dev(c, s.d_sum, 8)) ||
+            (rc = grow_dev(c, s.d_tab, nb * sizeof(redux_block))) || (rc = grow_pinned(c, s.h_off, (nb + 1) * 8)) ||
+            (rc = grow_pinned(c, s.h_st, nb * 4)) || (rc = grow_pinned(c, s.h_sum, 8)) || (rc = grow_pinned(c, s.h_tab, nb * sizeof(redux_block))))
+            return rc;
+        memcpy(s.h_tab.p, tbl.data(), nb * sizeof(redux_block));
+        HOST_TRY(hipMemcpyAsync(s.d_tab.p, s.h_tab.p, nb * sizeof(redux_block), hipMemcpyHostToDevice, st));
+        for (uint64_t k = 0; k < i1 - i0; k++)
+            if (in_len[i0 + k] && (rc = stage_h2d(c, pool, piece_no, (uint8_t *)s.d_in.p + doff[k], in + in_off[i0 + k], in_len[i0 + k], st)))
+                return rc;
+        HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
+        uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
+        if ((rc = redux_encode_blocks_v_dev(p, s.d_in.p, pos, s.d_tab.p, nb, block_size, REDUX_V_ALIGNED16, s.d_out.p, bound, s.d_off.p,
+                                            s.d_st.p, s.d_sum.p, ws, ws_bytes, st)))
+            return rc;
+        HOST_TRY(hipMemcpyAsync(s.h_off.p, s.d_off.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
+        HOST_TRY(hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st));
+        HOST_TRY(hipMemcpyAsync(s.h_sum.p, s.d_sum.p, 8, hipMemcpyDeviceToHost, st));
+        HOST_TRY(hipStreamSynchronize(st));
+        const uint64_t *ho    = (const uint64_t *)s.h_off.p;
+        const uint64_t  total = ho[nb];
+        if (out_base + total > out_cap)
+            return REDUX_OUTPUT_TOO_SMALL;
+        if (total && (rc = drain_d2h(c, out + out_base, s.d_out.p, total)))
+            return rc;
+        for (uint64_t i = 0; i <= nb; i++)
+            out_offsets[blk_base + i] = out_base + ho[i];
+        if (block_status)
+            memcpy(block_status + blk_base, s.h_st.p, nb * 4);
+        if (first_bad == REDUX_OK && ((const int32_t *)s.h_sum.p)[0] != REDUX_OK)
+            first_bad = ((const int32_t *)s.h_sum.p)[0];
+        blk_base += nb;
+        out_base += total;
+        i0 = i1;
+    }
+    return first_bad;
+}
+
+static int decode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint8_t *out, const uint64_t *out_off,
+                           const uint64_t *out_len, uint64_t ninputs, uint32_t block_size, uint32_t *out_sizes, int32_t *block_status,
+                           DecodeDevCall dev_call)
+{
+    Ctx *cp = nullptr;
+    int  rc = ctx_of_current_device(&cp);
+    if (rc != REDUX_OK)
+        return rc;
+    Ctx &c = *cp;
+    std::lock_guard<std::mutex> lock(c.mu);
+    if ((rc = ctx_init_locked(c)) != REDUX_OK)
+        return rc;
+    Slot       &s  = c.slot[0];
+    hipStream_t st = c.stream[0];
+    CopyPool    pool(kCopyThreads - 1);
+    uint64_t    piece_no = 0, blk_base = 0;
+    int         first_bad = REDUX_OK;
+    std::vector<uint64_t>    doff;
+    std::vector<redux_block> tbl;
+    for (uint64_t i0 = 0; i0 < ninputs;) {
+        uint64_t i1 = i0, pos = 0;
+        doff.clear();
+        do {
+            doff.push_back(pos);
+            pos += (out_len[i1] + 15) & ~15ull;
+            i1++;
+        } while (i1 < ninputs && pos + out_len[i1] <= kVGroupBytes);
+        const uint64_t nb = redux_block_count_v(out_len + i0, i1 - i0, block_size);
+        tbl.resize(nb);
+        redux_block_table_v(doff.data(), out_len + i0, i1 - i0, block_size, tbl.data()); // offset = where the block goes, length = its room
+        const uint64_t sb0 = in_offsets[blk_base];
+        for (uint64_t i = 0; i < nb; i++)
+            if (in_offsets[blk_base + i + 1] < in_offsets[blk_base + i])
+                return REDUX_INVALID_INPUT;
+        const uint64_t len_in = in_offsets[blk_base + nb] - sb0;
+        if (len_in && !in)
+            return REDUX_INVALID_INPUT;
+        const uint64_t wsb = redux_decode_workspace_bytes(p, nb, block_size);
+        if ((rc = grow_dev(c, s.d_in, len_in + 32)) || (rc = grow_dev(c, s.d_ws, wsb + 256)) || (rc = grow_dev(c, s.d_out, pos + 16)) ||
+            (rc = grow_dev(c, s.d_off, (nb + 1) * 8)) || (rc = grow_dev(c, s.d_sz, nb * 4)) || (rc = grow_dev(c, s.d_st, nb * 4)) ||
+            (rc = grow_dev(c, s.d_sum, 8)) || (rc = grow_dev(c, s.d_tab, nb * sizeof(redux_block))) ||
+            (rc = grow_pinned(c, s.h_off, (nb + 1) * 8)) || (rc = grow_pinned(c, s.h_sz, nb * 4)) || (rc = grow_pinned(c, s.h_st, nb * 4)) ||
+            (rc = grow_pinned(c, s.h_sum, 8)) || (rc = grow_pinned(c, s.h_tab, nb * sizeof(redux_block))))
+            return rc;
+        uint64_t *ho = (uint64_t *)s.h_off.p;
+        for (uint64_t i = 0; i <= nb; i++)
+            ho[i] = in_offsets[blk_base + i] - sb0;
+        memcpy(s.h_tab.p, tbl.data(), nb * sizeof(redux_block));
+        HOST_TRY(hipMemcpyAsync(s.d_off.p, ho, (nb + 1) * 8, hipMemcpyHostToDevice, st));
+        HOST_TRY(hipMemcpyAsync(s.d_tab.p, s.h_tab.p, nb * sizeof(redux_block), hipMemcpyHostToDevice, st));
+        if (len_in && (rc = stage_h2d(c, pool, piece_no, s.d_in.p, in + sb0, len_in, st)))
+            return rc;
+        HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
+        uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
+        if ((rc = dev_call(p, s.d_in.p, s.d_off.p, nb, block_size, s.d_out.p, pos, s.d_sz.p, s.d_st.p, s.d_sum.p, ws, wsb, st, nullptr,
+                           (const redux_block *)s.d_tab.p, true)))
+            return rc;
+        HOST_TRY(hipMemcpyAsync(s.h_sz.p, s.d_sz.p, nb * 4, hipMemcpyDeviceToHost, st));
+        HOST_TRY(hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st));
+        HOST_TRY(hipMemcpyAsync(s.h_sum.p, s.d_sum.p, 8, hipMemcpyDeviceToHost, st));
+        HOST_TRY(hipStreamSynchronize(st));
+        const uint32_t *hs = (const uint32_t *)s.h_sz.p;
+        // an input's blocks are back to back in both buffers: whole runs of full blocks leave as one copy
+        uint64_t b = 0;
+        for (uint64_t k = 0; k < i1 - i0; k++) {
+            const uint64_t cnt = redux_block_count(out_len[i0 + k], block_size);
+            for (uint64_t j = 0; j < cnt;) {
+                uint64_t run = 0, j1 = j;
+                while (j1 < cnt) { // extend over blocks that decoded to a whole block_size; the first shorter one ends the run
+                    const uint32_t sz = hs[b + j1];
+                    run += sz;
+                    j1++;
+                    if (sz != block_size)
+                        break;
+                }
+                if (run && (rc = drain_d2h(c, out + out_off[i0 + k] + j * (uint64_t)block_size,
+                                           (const uint8_t *)s.d_out.p + doff[k] + j * (uint64_t)block_size, run)))
+                    return rc;
+                j = j1;
+            }
+            b += cnt;
+        }
+        memcpy(out_sizes + blk_base, hs, nb * 4);
+        if (block_status)
+            memcpy(block_status + blk_base, s.h_st.p, nb * 4);
+        if (first_bad == REDUX_OK && ((const int32_t *)s.h_sum.p)[0] != REDUX_OK)
+            first_bad = ((const int32_t *)s.h_sum.p)[0];
+        blk_base += nb;
+        i0 = i1;
+    }
     return first_bad;
 }
 

@@ -147,3 +147,18 @@ def test_static_table_check_is_host_side():
     assert L.redux_static_table_check(C.byref(_lib.Params(12, 20, 32)), tab(flat)) == _lib.UNSUPPORTED
     assert L.redux_static_encode_workspace_bytes(C.byref(ok), 1 << 20, 65536) > 0
     assert L.redux_static_encode_bound(C.byref(ok), 1 << 20, 65536) >= (1 << 20) * 4
+
+
+def test_block_table_v_is_host_logic_and_orders_whole_blocks_first():
+    # redux_block_table_v / redux_block_count_v (the `_v` calls' geometry): no device call
+    tab = api.block_table_v([0, 1000, 5000], [10, 2 * 4096 + 3, 4096], 4096)
+    assert [int(e["index"]) for e in tab] == [1, 2, 4, 0, 3]          # whole blocks in block order, then tails, longest first
+    assert [int(e["length"]) for e in tab] == [4096, 4096, 4096, 10, 3]
+    assert [int(e["offset"]) for e in tab] == [1000, 1000 + 4096, 5000, 0, 1000 + 8192]
+    L = _lib.lib()
+    lens = np.array([0, 1, 4096, 4097, 0], dtype=np.uint64)
+    assert L.redux_block_count_v(lens.ctypes.data, 5, 4096) == 1 + 1 + 1 + 2 + 1   # an empty input is one empty block
+    assert L.redux_block_count_v(lens.ctypes.data, 5, 0) == 0
+    tab = api.block_table_v([0, 0, 0, 0, 0], lens, 4096)
+    assert sorted(int(e["index"]) for e in tab) == list(range(6))
+    assert api.BLOCK_DTYPE.itemsize == 16

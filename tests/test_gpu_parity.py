@@ -1023,3 +1023,73 @@ def test_lockstep_kernels_for_4_and_12_bit_symbols(rx, params):
         assert stw == 0 and dec[b * BLOCK: b * BLOCK + int(sizes[b])].tobytes() == outw, (params, b)
         keep = len(blk) * 8 // params[0] * params[0] // 8   # whole symbols, whole bytes
         assert outw == blk[:keep]
+
+
+# ---- many independent inputs in one call (BASELINE.json configs[2]; reference harness tests/corpora.rs:32-85) ----
+def _all_corpus_files():
+    return corpus_files("artificial", "calgary", "canterbury", "large", "misc")
+
+
+@pytest.mark.parametrize("w", WIDTHS)
+def test_all_corpus_files_in_one_call_match_the_golden_blocks(rx, w):
+    """Every file of every corpus through redux_encode_blocks_v: ONE launch, each file cut into 64 KiB blocks on its own
+    (ragged tails, no padding); every block against tests/golden/blocks.json; one redux_decode_blocks_v back."""
+    files = _all_corpus_files()
+    datas = [open(path, "rb").read() for _, path in files]
+    gold = json.load(open(os.path.join(GOLDEN, "blocks.json")))
+    out, offs, st, first = rx.compress_blocks_v(datas, BLOCK, w)
+    assert (st == 0).all() and int(first[-1]) == len(offs) - 1
+    streams = split(out, offs)
+    for i, (key, _) in enumerate(files):
+        g = gold[key]["%d_%d_%d" % w]
+        mine = streams[int(first[i]): int(first[i + 1])]
+        assert [len(s) for s in mine] == g["block_sizes"], (key, w)
+        assert [h64(s) for s in mine] == g["block_hashes"], (key, w)
+    dec, sizes, dst = rx.decompress_blocks_v(out, offs, [len(d) for d in datas], BLOCK, w)
+    assert (dst == 0).all()
+    for d, got in zip(datas, dec):
+        assert got.tobytes() == d
+
+
+def test_batch_call_equals_per_input_calls_on_ragged_inputs(rx):
+    """Inputs of awkward lengths (0, 1, one block exactly, one block + 1, ...) at a small block size: the batch call must
+    give, block for block, what redux_encode_blocks gives for each input alone, and decode back."""
+    rng = np.random.default_rng(0x5EED0B)
+    bs = 4096
+    lens = [0, 1, 15, 16, 17, bs - 1, bs, bs + 1, 3 * bs, 3 * bs + 5, 100, 0, 7 * bs + 4095, 64 * bs, 64 * bs + 1]
+    datas = [bytes((rng.integers(0, 256, n, dtype=np.uint8) >> rng.integers(0, 7)).tolist()) for n in lens]
+    for w in [(8, 30, 32), (8, 14, 16)]:
+        out, offs, st, first = rx.compress_blocks_v(datas, bs, w)
+        streams = split(out, offs)
+        for i, d in enumerate(datas):
+            o1, of1, _ = rx.compress_blocks(d, bs, w)
+            assert streams[int(first[i]): int(first[i + 1])] == split(o1, of1), (i, len(d), w)
+        dec, sizes, dst = rx.decompress_blocks_v(out, offs, lens, bs, w)
+        assert [g.tobytes() for g in dec] == datas
+
+
+def test_block_table_v_orders_whole_blocks_first(rx):
+    tab = rx.block_table_v([0, 1000, 5000], [10, 2 * 4096 + 3, 4096], 4096)
+    assert [int(e["index"]) for e in tab] == [1, 2, 4, 0, 3]          # whole blocks in block order, then tails, longest first
+    assert [int(e["length"]) for e in tab] == [4096, 4096, 4096, 10, 3]
+    assert [int(e["offset"]) for e in tab] == [1000, 1000 + 4096, 5000, 0, 1000 + 8192]
+
+
+def test_batch_decode_reports_damage_per_block_and_stays_inside_each_input(rx):
+    """A damaged stream in the middle of a batch: its block reports the error, the other inputs decode, and nothing is
+    written outside an input's own out_len bytes (the tail block of an input has less room than block_size)."""
+    rng = np.random.default_rng(7)
+    bs = 4096
+    datas = [bytes(rng.integers(0, 256, n, dtype=np.uint8).tolist()) for n in (5000, 300, 9000)]
+    out, offs, st, first = rx.compress_blocks_v(datas, bs, (8, 30, 32))
+    bad = out.copy()
+    b = int(first[1])                       # the only block of input 1: claim more symbols than it has room for
+    other, oo, _ = rx.compress_blocks(bytes(rng.integers(0, 256, 2000, dtype=np.uint8).tolist()), bs, (8, 30, 32))
+    streams = split(bad, offs)
+    streams[b] = other.tobytes()            # a valid stream of 2000 bytes where 300 are expected
+    offs2 = np.zeros(len(offs), dtype=np.uint64)
+    offs2[1:] = np.cumsum([len(s) for s in streams])
+    dec, sizes, dst = rx.decompress_blocks_v(np.frombuffer(b"".join(streams), dtype=np.uint8), offs2, [len(d) for d in datas], bs,
+                                             (8, 30, 32), check=False)
+    assert int(dst[b]) == 4 and int(sizes[b]) == 300          # OutputTooSmall, 300 bytes written
+    assert dec[0].tobytes() == datas[0] and dec[2].tobytes() == datas[2]
