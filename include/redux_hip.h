@@ -60,8 +60,10 @@ typedef struct redux_params {
 typedef struct redux_block {
     uint64_t offset; /* encode: the block's first byte in the input buffer; decode: where its output starts */
     uint32_t length; /* encode: bytes in the block (<= block_size); decode: output capacity (<= block_size) */
-    uint32_t index;  /* the block's number: its entry in out_offsets / in_offsets / out_sizes / block_status */
+    uint32_t index;  /* the block's number: its entry in out_offsets / in_offsets / out_sizes / block_status;
+                        REDUX_BLOCK_IDLE: no block, the lane idles (padding, see redux_block_table_v) */
 } redux_block;
+#define REDUX_BLOCK_IDLE 0xFFFFFFFFu
 
 /* model::Parameters::new validation, src/model/mod.rs:64: OK or INVALID_INPUT. */
 int redux_params_check(uint32_t symbol_bits, uint32_t freq_bits, uint32_t code_bits);
@@ -113,10 +115,15 @@ int redux_decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t
  * in_len[i], block_size) - 1, first(0) = 0.  One launch codes all of them.
  *
  * redux_block_count_v   total number of blocks.
- * redux_block_table_v   the block table of these inputs in LAUNCH order: whole blocks first,
- *                       then the shorter ones by decreasing length, so that the 64 lanes of a
- *                       wave have the same amount of work; entry.index = the block's number.
- *                       `table` may be NULL (count only).  Returns the number of blocks.
+ * redux_block_table_v   the block table of these inputs in LAUNCH order.  A wave (64 consecutive
+ *                       entries) runs its fast path for as long as its SHORTEST block lasts, so
+ *                       the table puts whole blocks first, 64 to a wave, then the shorter ones by
+ *                       decreasing length, and starts a new wave wherever the length has dropped
+ *                       by an eighth: the rest of the old wave is filled with IDLE entries
+ *                       (index = REDUX_BLOCK_IDLE; on a chip with 1024 wave slots a batch of a
+ *                       few hundred blocks has lanes to spare).  entry.index = the block's number
+ *                       otherwise.  Returns the number of ENTRIES (>= blocks); `table` may be
+ *                       NULL (count only).
  * redux_encode_blocks_v out / out_offsets (total blocks + 1) / block_status (may be NULL) as in
  *                       redux_encode_blocks, in block-number order.
  * redux_decode_blocks_v the inverse: in / in_offsets as produced above; input i's blocks are
@@ -176,17 +183,18 @@ int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void 
  * entry.offset is where the block's output starts in d_out (out_bytes = size of that buffer),
  * entry.length the room it has there.  flags: REDUX_V_ALIGNED16 promises that d_in / d_out and
  * every entry.offset are multiples of 16 (the fast kernels need it; without it the call is
- * correct and slow).  Workspace: redux_encode_workspace_bytes(p, nblocks * block_size, block_size)
- * / redux_decode_workspace_bytes(p, nblocks, block_size). */
+ * correct and slow).  nentries = entries of the table (idle ones included), nblocks = blocks.
+ * Workspace: redux_encode_workspace_bytes(p, nentries * block_size, block_size) /
+ * redux_decode_workspace_bytes(p, nentries, block_size). */
 enum { REDUX_V_ALIGNED16 = 1 };
 int redux_encode_blocks_v_dev(const redux_params *p, const void *d_in, uint64_t in_bytes, const void *d_table,
-                              uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out, uint64_t out_cap,
-                              void *d_out_offsets, void *d_block_status, void *d_summary, void *d_workspace,
-                              uint64_t workspace_bytes, void *stream);
-int redux_decode_blocks_v_dev(const redux_params *p, const void *d_in, const void *d_in_offsets, const void *d_table,
-                              uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out, uint64_t out_bytes,
-                              void *d_out_sizes, void *d_block_status, void *d_summary, void *d_workspace,
-                              uint64_t workspace_bytes, void *stream);
+                              uint64_t nentries, uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out,
+                              uint64_t out_cap, void *d_out_offsets /* u64[nblocks+1] */, void *d_block_status /* i32[nblocks] */,
+                              void *d_summary, void *d_workspace, uint64_t workspace_bytes, void *stream);
+int redux_decode_blocks_v_dev(const redux_params *p, const void *d_in, const void *d_in_offsets /* u64[nblocks+1] */,
+                              const void *d_table, uint64_t nentries, uint64_t nblocks, uint32_t block_size, uint32_t flags,
+                              void *d_out, uint64_t out_bytes, void *d_out_sizes /* u32[nblocks] */, void *d_block_status,
+                              void *d_summary, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* The two phases of redux_encode_blocks_dev, exposed so a harness can time the coder kernel
  * by itself: (1) code every block into its padded slot inside the workspace and record the

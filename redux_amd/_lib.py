@@ -41,8 +41,8 @@ SIGNATURES = {
     "redux_block_table_v": (_U64, [_V, _V, _U64, _U32, _V]),
     "redux_encode_blocks_v": (C.c_int, [_PP, _V, _V, _V, _U64, _U32, _V, _U64, _V, _V]),
     "redux_decode_blocks_v": (C.c_int, [_PP, _V, _V, _V, _V, _V, _U64, _U32, _V, _V]),
-    "redux_encode_blocks_v_dev": (C.c_int, [_PP, _V, _U64, _V, _U64, _U32, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
-    "redux_decode_blocks_v_dev": (C.c_int, [_PP, _V, _V, _V, _U64, _U32, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
+    "redux_encode_blocks_v_dev": (C.c_int, [_PP, _V, _U64, _V, _U64, _U64, _U32, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
+    "redux_decode_blocks_v_dev": (C.c_int, [_PP, _V, _V, _V, _U64, _U64, _U32, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
     "redux_compress": (C.c_int, [_PP, _V, _U64, _V, _U64, C.POINTER(_U64), C.POINTER(_U64)]),
     "redux_decompress": (C.c_int, [_PP, _V, _U64, _V, _U64, C.POINTER(_U64), C.POINTER(_U64)]),
     "redux_host_release": (C.c_int, []),

@@ -178,6 +178,7 @@ def decompress_blocks(streams, offsets, block_size, params=(8, 30, 32), check=Tr
 
 # ---- many independent inputs in one call (tests/corpora.rs:32-85 codes file by file) --------
 BLOCK_DTYPE = np.dtype([("offset", "<u8"), ("length", "<u4"), ("index", "<u4")])  # redux_block
+BLOCK_IDLE = 0xFFFFFFFF  # REDUX_BLOCK_IDLE
 
 
 def block_table_v(offsets, lengths, block_size):
@@ -185,8 +186,8 @@ def block_table_v(offsets, lengths, block_size):
     off = np.ascontiguousarray(offsets, dtype=np.uint64)
     ln = np.ascontiguousarray(lengths, dtype=np.uint64)
     L = _lib.lib()
-    nb = L.redux_block_count_v(ln.ctypes.data, len(ln), block_size)
-    tab = np.zeros(nb, dtype=BLOCK_DTYPE)
+    ne = L.redux_block_table_v(off.ctypes.data, ln.ctypes.data, len(ln), block_size, None)  # entries: blocks + idle lanes
+    tab = np.zeros(ne, dtype=BLOCK_DTYPE)
     L.redux_block_table_v(off.ctypes.data, ln.ctypes.data, len(ln), block_size, tab.ctypes.data)
     return tab
 

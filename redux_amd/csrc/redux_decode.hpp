@@ -36,7 +36,8 @@ struct DecArgs {
     uint64_t       *in_used;    // optional: bytes of each stream the reader fetched (ByteCount, bitio/mod.rs:71)
     // Block table (redux_decode_blocks_v_dev; null: slot j decodes block j to out + j * block_size, capacity block_size).
     // Entry j: the block numbered `index` (its stream is in_offsets[index] .., its size / status go to entry `index`) is
-    // written at out + offset and may hold `length` <= block_size bytes.
+    // written at out + offset and may hold `length` <= block_size bytes; index 0xFFFFFFFF: an idle lane.  nblocks counts
+    // table entries then.
     const redux_block *table;
 };
 
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
     constexpr int  KS   = Tree<U16>::kShift;
     const uint32_t lane = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * 64 + lane;
-    const bool     live = slot < a.nblocks;
+    const bool     live = slot < a.nblocks && !(a.table && a.table[slot].index == 0xFFFFFFFFu /* idle entry */);
     uint64_t       blk = slot, dst_off = slot * (uint64_t)a.block_size;
     uint32_t       capn = a.block_size;
     if (a.table && live) { // block table: see DecArgs

@@ -145,7 +145,7 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
 {
     const uint32_t lane = threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * 64 + lane;
-    const bool     live = slot < a.nblocks;
+    const bool     live = slot < a.nblocks && !(a.table && a.table[slot].index == 0xFFFFFFFFu /* idle entry */);
 
     AdTree A;
     A.init(lds, lane);

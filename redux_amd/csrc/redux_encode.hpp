@@ -54,6 +54,11 @@ struct EncArgs {
     const redux_block *table;
 };
 
+// A table entry with this index is an idle lane: redux_block_table_v pads the table with them so that blocks of very
+// different lengths do not share a wave (a wave runs its fast path for as long as its shortest block lasts).  Its
+// offset still names readable input bytes (the lane runs the instruction stream on them and stores into its own slot).
+constexpr uint32_t kIdleEntry = 0xFFFFFFFFu;
+
 // what a lane codes: source offset from the wave's base, length, and where its results go
 struct EncLane {
     uint32_t soff, len;
@@ -67,7 +72,7 @@ __device__ __forceinline__ EncLane enc_lane(const EncArgs &a, uint64_t blk0, uin
         wsrc   = a.in;
         L.soff = (uint32_t)e.offset;
         L.len  = live ? e.length : 0u;
-        L.ob   = e.index;
+        L.ob   = e.index; // (an idle entry, index kIdleEntry: never used -- the caller's `live` is false for it)
     } else {
         wsrc   = a.in + blk0 * a.block_size;
         L.soff = live ? lane * a.block_size : 0u;
@@ -133,7 +138,7 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
     const uint32_t lane = threadIdx.x;
     const uint64_t blk0 = (uint64_t)blockIdx.x * a.lanes; // wave-uniform
     const uint64_t blk  = blk0 + lane;
-    const bool     live = lane < a.lanes && blk < a.nblocks;
+    const bool     live = lane < a.lanes && blk < a.nblocks && !(a.table && a.table[blk].index == kIdleEntry);
 
     for (uint32_t i = lane; i < Tree<U16>::kDwords / 4; i += 64)
         reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
@@ -700,7 +705,7 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t blk0 = (uint64_t)blockIdx.x * a.lanes;
     const uint64_t blk  = blk0 + lane;
-    const bool     live = lane < a.lanes && blk < a.nblocks;
+    const bool     live = lane < a.lanes && blk < a.nblocks && !(a.table && a.table[blk].index == kIdleEntry);
 
     for (uint32_t i = threadIdx.x; i < Tree<true>::kDwords / 4; i += 128)
         reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);

@@ -498,7 +498,7 @@ int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_
 // scan + gather of the slots a coder kernel left in the workspace laid out by g
 static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *d_out_offsets, void *d_block_status,
                         void *d_summary, void *d_workspace, uint64_t workspace_bytes, void *stream,
-                        const redux_block *d_table = nullptr)
+                        const redux_block *d_table = nullptr, uint64_t nblocks_real = 0)
 {
     if (!d_workspace || !d_block_status || !d_out_offsets || !d_out)
         return REDUX_INVALID_INPUT;
@@ -512,7 +512,7 @@ static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *
     sa.status  = (const int32_t *)d_block_status;
     sa.offsets = (uint64_t *)d_out_offsets;
     sa.summary = (int32_t *)d_summary;
-    sa.nblocks = g.nblocks;
+    sa.nblocks = d_table ? nblocks_real : g.nblocks; // (g counts slots = table entries; sizes and status are per block)
     if (scan_is_coalesced(sa))
         k_scan_sizes_coalesced<<<1, 1024, 0, s>>>(sa);
     else
@@ -567,18 +567,18 @@ int redux_encode_blocks_dev(const redux_params *p, const void *d_in, uint64_t in
 }
 
 int redux_encode_blocks_v_dev(const redux_params *p, const void *d_in, uint64_t in_bytes, const void *d_table,
-                              uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out, uint64_t out_cap,
-                              void *d_out_offsets, void *d_block_status, void *d_summary, void *d_workspace,
+                              uint64_t nentries, uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out,
+                              uint64_t out_cap, void *d_out_offsets, void *d_block_status, void *d_summary, void *d_workspace,
                               uint64_t workspace_bytes, void *stream)
 {
-    if (!d_table)
+    if (!d_table || nblocks == 0 || nentries < nblocks)
         return REDUX_INVALID_INPUT;
-    int st = encode_slots_impl(p, d_in, in_bytes, block_size, (const redux_block *)d_table, nblocks,
+    int st = encode_slots_impl(p, d_in, in_bytes, block_size, (const redux_block *)d_table, nentries,
                                (flags & REDUX_V_ALIGNED16) != 0, d_block_status, d_workspace, workspace_bytes, stream);
     if (st != REDUX_OK)
         return st;
-    return compact_with(geometry(p, nblocks * (uint64_t)block_size, block_size), d_out, out_cap, d_out_offsets, d_block_status,
-                        d_summary, d_workspace, workspace_bytes, stream, (const redux_block *)d_table);
+    return compact_with(geometry(p, nentries * (uint64_t)block_size, block_size), d_out, out_cap, d_out_offsets, d_block_status,
+                        d_summary, d_workspace, workspace_bytes, stream, (const redux_block *)d_table, nblocks);
 }
 
 uint64_t redux_block_count_v(const uint64_t *in_len, uint64_t ninputs, uint32_t block_size)
@@ -595,11 +595,11 @@ uint64_t redux_block_table_v(const uint64_t *in_off, const uint64_t *in_len, uin
                              redux_block *table)
 {
     const uint64_t nb = redux_block_count_v(in_len, ninputs, block_size);
-    if (!table || nb == 0 || nb > 0xFFFFFFFFull || !in_off)
-        return nb;
+    if (nb == 0 || nb > 0xFFFFFFF0ull || !in_off)
+        return 0;
     // whole blocks first, in block order; then the short ones (at most one per input), longest first
-    std::vector<redux_block> tails;
-    uint64_t k = 0, b = 0;
+    std::vector<redux_block> whole, tails;
+    uint64_t b = 0;
     for (uint64_t i = 0; i < ninputs; i++) {
         const uint64_t cnt = redux_block_count(in_len[i], block_size);
         for (uint64_t j = 0; j < cnt; j++, b++) {
@@ -609,16 +609,28 @@ uint64_t redux_block_table_v(const uint64_t *in_off, const uint64_t *in_len, uin
             e.offset = in_off[i] + o;
             e.length = rem < block_size ? (uint32_t)rem : block_size;
             e.index  = (uint32_t)b;
-            if (e.length == block_size)
-                table[k++] = e;
-            else
-                tails.push_back(e);
+            (e.length == block_size ? whole : tails).push_back(e);
         }
     }
     std::stable_sort(tails.begin(), tails.end(), [](const redux_block &x, const redux_block &y) { return x.length > y.length; });
-    for (const redux_block &e : tails)
-        table[k++] = e;
-    return nb;
+    // a new wave wherever the length has dropped by an eighth (small blocks: by 512 bytes) since the wave's first entry
+    std::vector<redux_block> t(whole);
+    const redux_block idle = {0, 0, REDUX_BLOCK_IDLE};
+    uint32_t first_len = block_size;
+    for (const redux_block &e : tails) {
+        const uint32_t slack = first_len / 8 > 512 ? first_len / 8 : 512;
+        if (t.size() % 64 == 0)
+            first_len = e.length;
+        else if (e.length + slack < first_len) {
+            while (t.size() % 64)
+                t.push_back(idle);
+            first_len = e.length;
+        }
+        t.push_back(e);
+    }
+    if (table)
+        memcpy(table, t.data(), t.size() * sizeof(redux_block));
+    return t.size();
 }
 
 int redux_encode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len,
@@ -681,7 +693,7 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
                                   uint32_t block_size, void *d_out, uint64_t out_cap, void *d_out_sizes,
                                   void *d_block_status, void *d_summary, void *d_workspace,
                                   uint64_t workspace_bytes, void *stream, void *d_in_used,
-                                  const redux_block *d_table = nullptr, bool tbl_aligned16 = false)
+                                  const redux_block *d_table = nullptr, bool tbl_aligned16 = false, uint64_t nblocks_real = 0)
 {
     int st = check_params(p);
     if (st != REDUX_OK)
@@ -774,8 +786,8 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     case DecKernel::Gen12:
     case DecKernel::Any: break; // handled above
     }
-    if (d_summary)
-        k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
+    if (d_summary) // (with a block table nblocks counts its entries: statuses are per block)
+        k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, d_table ? nblocks_real : nblocks, (int32_t *)d_summary);
     HIP_TRY(hipGetLastError());
     return REDUX_OK;
 }
@@ -817,15 +829,15 @@ int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void 
 }
 
 int redux_decode_blocks_v_dev(const redux_params *p, const void *d_in, const void *d_in_offsets, const void *d_table,
-                              uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out, uint64_t out_bytes,
-                              void *d_out_sizes, void *d_block_status, void *d_summary, void *d_workspace,
+                              uint64_t nentries, uint64_t nblocks, uint32_t block_size, uint32_t flags, void *d_out,
+                              uint64_t out_bytes, void *d_out_sizes, void *d_block_status, void *d_summary, void *d_workspace,
                               uint64_t workspace_bytes, void *stream)
 {
-    if (!d_table || (nblocks && !d_out))
+    if (!d_table || nblocks == 0 || nentries < nblocks || !d_out)
         return REDUX_INVALID_INPUT;
-    return decode_blocks_dev_impl(p, d_in, d_in_offsets, nblocks, block_size, d_out, out_bytes, d_out_sizes, d_block_status,
+    return decode_blocks_dev_impl(p, d_in, d_in_offsets, nentries, block_size, d_out, out_bytes, d_out_sizes, d_block_status,
                                   d_summary, d_workspace, workspace_bytes, stream, nullptr, (const redux_block *)d_table,
-                                  (flags & REDUX_V_ALIGNED16) != 0);
+                                  (flags & REDUX_V_ALIGNED16) != 0, nblocks);
 }
 
 int redux_decode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint8_t *out,

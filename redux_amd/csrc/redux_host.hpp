@@ -464,7 +464,7 @@ static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_l
 // ================================================================================================
 // decode_blocks_dev_impl of redux_hip.hip (defined after this header is included)
 typedef int (*DecodeDevCall)(const redux_params *, const void *, const void *, uint64_t, uint32_t, void *, uint64_t, void *, void *,
-                             void *, void *, uint64_t, void *, void *, const redux_block *, bool);
+                             void *, void *, uint64_t, void *, void *, const redux_block *, bool, uint64_t);
 
 static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
                          uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes, int32_t *block_status,
@@ -584,7 +584,7 @@ static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_
                 HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
                 uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
                 r = dev_call(p, s.d_in.p, s.d_off.p, nb, block_size, s.d_out.p, nb * (uint64_t)block_size, s.d_sz.p, s.d_st.p,
-                             s.d_sum.p, ws, wsb, st, in_used ? s.d_used.p : nullptr, nullptr, false);
+                             s.d_sum.p, ws, wsb, st, in_used ? s.d_used.p : nullptr, nullptr, false, 0);
                 if (r != REDUX_OK)
                     return r;
                 HOST_TRY(hipEventRecord(s.done, st)); // (small result arrays: fetched by the drain thread, see encode_blocks)
@@ -651,23 +651,24 @@ static int encode_blocks_v(const redux_params *p, const uint8_t *in, const uint6
         if (pos > 0xFFFFFFFFull) // (one input of 4 GiB or more: lane offsets are 32-bit; redux_encode_blocks takes it)
             return REDUX_UNSUPPORTED;
         const uint64_t nb = redux_block_count_v(in_len + i0, i1 - i0, block_size);
-        tbl.resize(nb);
+        const uint64_t ne = redux_block_table_v(doff.data(), in_len + i0, i1 - i0, block_size, nullptr); // entries: blocks + idle lanes
+        tbl.resize(ne);
         redux_block_table_v(doff.data(), in_len + i0, i1 - i0, block_size, tbl.data());
-        const uint64_t ws_bytes = redux_encode_workspace_bytes(p, nb * (uint64_t)block_size, block_size);
+        const uint64_t ws_bytes = redux_encode_workspace_bytes(p, ne * (uint64_t)block_size, block_size);
         const uint64_t bound    = nb * redux_encode_slot_bytes(p, block_size);
         if ((rc = grow_dev(c, s.d_in, pos + 16)) || (rc = grow_dev(c, s.d_ws, ws_bytes + 256)) || (rc = grow_dev(c, s.d_out, bound + 16)) ||
             (rc = grow_dev(c, s.d_off, (nb + 1) * 8)) || (rc = grow_dev(c, s.d_st, nb * 4)) || (rc = grow_dev(c, s.d_sum, 8)) ||
-            (rc = grow_dev(c, s.d_tab, nb * sizeof(redux_block))) || (rc = grow_pinned(c, s.h_off, (nb + 1) * 8)) ||
-            (rc = grow_pinned(c, s.h_st, nb * 4)) || (rc = grow_pinned(c, s.h_sum, 8)) || (rc = grow_pinned(c, s.h_tab, nb * sizeof(redux_block))))
+            (rc = grow_dev(c, s.d_tab, ne * sizeof(redux_block))) || (rc = grow_pinned(c, s.h_off, (nb + 1) * 8)) ||
+            (rc = grow_pinned(c, s.h_st, nb * 4)) || (rc = grow_pinned(c, s.h_sum, 8)) || (rc = grow_pinned(c, s.h_tab, ne * sizeof(redux_block))))
             return rc;
-        memcpy(s.h_tab.p, tbl.data(), nb * sizeof(redux_block));
-        HOST_TRY(hipMemcpyAsync(s.d_tab.p, s.h_tab.p, nb * sizeof(redux_block), hipMemcpyHostToDevice, st));
+        memcpy(s.h_tab.p, tbl.data(), ne * sizeof(redux_block));
+        HOST_TRY(hipMemcpyAsync(s.d_tab.p, s.h_tab.p, ne * sizeof(redux_block), hipMemcpyHostToDevice, st));
         for (uint64_t k = 0; k < i1 - i0; k++)
             if (in_len[i0 + k] && (rc = stage_h2d(c, pool, piece_no, (uint8_t *)s.d_in.p + doff[k], in + in_off[i0 + k], in_len[i0 + k], st)))
                 return rc;
         HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
         uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
-        if ((rc = redux_encode_blocks_v_dev(p, s.d_in.p, pos, s.d_tab.p, nb, block_size, REDUX_V_ALIGNED16, s.d_out.p, bound, s.d_off.p,
+        if ((rc = redux_encode_blocks_v_dev(p, s.d_in.p, pos, s.d_tab.p, ne, nb, block_size, REDUX_V_ALIGNED16, s.d_out.p, bound, s.d_off.p,
                                             s.d_st.p, s.d_sum.p, ws, ws_bytes, st)))
             return rc;
         HOST_TRY(hipMemcpyAsync(s.h_off.p, s.d_off.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
@@ -721,7 +722,8 @@ static int decode_blocks_v(const redux_params *p, const uint8_t *in, const uint6
             i1++;
         } while (i1 < ninputs && pos + out_len[i1] <= kVGroupBytes);
         const uint64_t nb = redux_block_count_v(out_len + i0, i1 - i0, block_size);
-        tbl.resize(nb);
+        const uint64_t ne = redux_block_table_v(doff.data(), out_len + i0, i1 - i0, block_size, nullptr);
+        tbl.resize(ne);
         redux_block_table_v(doff.data(), out_len + i0, i1 - i0, block_size, tbl.data()); // offset = where the block goes, length = its room
         const uint64_t sb0 = in_offsets[blk_base];
         for (uint64_t i = 0; i < nb; i++)
@@ -730,25 +732,25 @@ static int decode_blocks_v(const redux_params *p, const uint8_t *in, const uint6
         const uint64_t len_in = in_offsets[blk_base + nb] - sb0;
         if (len_in && !in)
             return REDUX_INVALID_INPUT;
-        const uint64_t wsb = redux_decode_workspace_bytes(p, nb, block_size);
+        const uint64_t wsb = redux_decode_workspace_bytes(p, ne, block_size);
         if ((rc = grow_dev(c, s.d_in, len_in + 32)) || (rc = grow_dev(c, s.d_ws, wsb + 256)) || (rc = grow_dev(c, s.d_out, pos + 16)) ||
             (rc = grow_dev(c, s.d_off, (nb + 1) * 8)) || (rc = grow_dev(c, s.d_sz, nb * 4)) || (rc = grow_dev(c, s.d_st, nb * 4)) ||
-            (rc = grow_dev(c, s.d_sum, 8)) || (rc = grow_dev(c, s.d_tab, nb * sizeof(redux_block))) ||
+            (rc = grow_dev(c, s.d_sum, 8)) || (rc = grow_dev(c, s.d_tab, ne * sizeof(redux_block))) ||
             (rc = grow_pinned(c, s.h_off, (nb + 1) * 8)) || (rc = grow_pinned(c, s.h_sz, nb * 4)) || (rc = grow_pinned(c, s.h_st, nb * 4)) ||
-            (rc = grow_pinned(c, s.h_sum, 8)) || (rc = grow_pinned(c, s.h_tab, nb * sizeof(redux_block))))
+            (rc = grow_pinned(c, s.h_sum, 8)) || (rc = grow_pinned(c, s.h_tab, ne * sizeof(redux_block))))
             return rc;
         uint64_t *ho = (uint64_t *)s.h_off.p;
         for (uint64_t i = 0; i <= nb; i++)
             ho[i] = in_offsets[blk_base + i] - sb0;
-        memcpy(s.h_tab.p, tbl.data(), nb * sizeof(redux_block));
+        memcpy(s.h_tab.p, tbl.data(), ne * sizeof(redux_block));
         HOST_TRY(hipMemcpyAsync(s.d_off.p, ho, (nb + 1) * 8, hipMemcpyHostToDevice, st));
-        HOST_TRY(hipMemcpyAsync(s.d_tab.p, s.h_tab.p, nb * sizeof(redux_block), hipMemcpyHostToDevice, st));
+        HOST_TRY(hipMemcpyAsync(s.d_tab.p, s.h_tab.p, ne * sizeof(redux_block), hipMemcpyHostToDevice, st));
         if (len_in && (rc = stage_h2d(c, pool, piece_no, s.d_in.p, in + sb0, len_in, st)))
             return rc;
         HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
         uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
-        if ((rc = dev_call(p, s.d_in.p, s.d_off.p, nb, block_size, s.d_out.p, pos, s.d_sz.p, s.d_st.p, s.d_sum.p, ws, wsb, st, nullptr,
-                           (const redux_block *)s.d_tab.p, true)))
+        if ((rc = dev_call(p, s.d_in.p, s.d_off.p, ne, block_size, s.d_out.p, pos, s.d_sz.p, s.d_st.p, s.d_sum.p, ws, wsb, st, nullptr,
+                           (const redux_block *)s.d_tab.p, true, nb)))
             return rc;
         HOST_TRY(hipMemcpyAsync(s.h_sz.p, s.d_sz.p, nb * 4, hipMemcpyDeviceToHost, st));
         HOST_TRY(hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st));

@@ -271,6 +271,8 @@ __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
     const uint32_t bx  = (mode & 2u) ? 3u : 0u;                   // slot byte that holds stream byte i: i ^ bx
     const uint32_t sel = (mode & 2u) ? 0x00010203u : 0x03020100u; // v_perm selector that restores stream order
     const uint64_t lb = a.table ? a.table[b].index : b;
+    if (lb == kIdleEntry) // an idle table entry: nothing was coded in this slot
+        return;
     const uint64_t o0 = a.offsets[lb], o1 = a.offsets[lb + 1];
     const uint32_t tid = threadIdx.x;
     if (o1 > a.out_cap) { // the dense buffer is too small for this block: report, never write
@@ -362,8 +364,8 @@ __global__ void __launch_bounds__(256) k_compact_rows(CompactArgs a)
         const uint64_t b = g * 64 + tid;
         uint64_t       d = 0;
         uint32_t       n = 0, sh = 0;
-        if (b < a.nblocks) {
-            const uint64_t lb = a.table ? a.table[b].index : b;
+        const uint64_t lb = b < a.nblocks ? (a.table ? a.table[b].index : b) : kIdleEntry;
+        if (lb != kIdleEntry) {
             const uint64_t o0 = a.offsets[lb], o1 = a.offsets[lb + 1];
             if (o1 <= a.out_cap) {
                 n  = (uint32_t)(o1 - o0);

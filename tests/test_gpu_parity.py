@@ -1070,9 +1070,12 @@ def test_batch_call_equals_per_input_calls_on_ragged_inputs(rx):
 
 def test_block_table_v_orders_whole_blocks_first(rx):
     tab = rx.block_table_v([0, 1000, 5000], [10, 2 * 4096 + 3, 4096], 4096)
-    assert [int(e["index"]) for e in tab] == [1, 2, 4, 0, 3]          # whole blocks in block order, then tails, longest first
-    assert [int(e["length"]) for e in tab] == [4096, 4096, 4096, 10, 3]
-    assert [int(e["offset"]) for e in tab] == [1000, 1000 + 4096, 5000, 0, 1000 + 8192]
+    live = tab[tab["index"] != api.BLOCK_IDLE] if "api" in globals() else tab[tab["index"] != 0xFFFFFFFF]
+    assert [int(e["index"]) for e in live] == [1, 2, 4, 0, 3]         # whole blocks in block order, then tails, longest first
+    assert [int(e["length"]) for e in live] == [4096, 4096, 4096, 10, 3]
+    assert [int(e["offset"]) for e in live] == [1000, 1000 + 4096, 5000, 0, 1000 + 8192]
+    # the tails do not share a wave with the whole blocks: idle entries fill the first wave
+    assert len(tab) == 66 and (tab["index"][3:64] == 0xFFFFFFFF).all() and int(tab["index"][64]) == 0
 
 
 def test_batch_decode_reports_damage_per_block_and_stays_inside_each_input(rx):

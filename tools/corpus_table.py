@@ -47,12 +47,119 @@ def timed(fn, reps=1):
     return r, best
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota (as bench.py)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+def batch(corpora, bits_list):
+    """--batch: the files of the named corpora through ONE redux_encode_blocks_v / redux_decode_blocks_v call each (no
+    padding: every file is cut into 64 KiB blocks on its own), next to the C restatement on one thread and on all host
+    threads (one block per task).  Two GPU figures: the host-pointer call as a caller sees it (staging, PCIe, launch,
+    copy back: wall clock), and the launches alone with everything resident in HBM (HIP events around the _v_dev call)."""
+    from redux_amd import _lib
+    L = _lib.lib()
+    names, datas = [], []
+    for corpus in corpora:
+        for f in sorted(os.listdir(os.path.join(GOLDEN, corpus))):
+            names.append(f"{corpus}/{f}")
+            datas.append(open(os.path.join(GOLDEN, corpus, f), "rb").read())
+    n = sum(len(d) for d in datas)
+    nthreads = host_cores()
+    print(f"# batch: {len(datas)} files of {'+'.join(corpora)}, {n} B, 64 KiB blocks per file (ragged tails), MiB/s = bytes / s / 2^20")
+    rx.compress_blocks_v([b"warm"], BLOCK, (8, 30, 32))
+    for bits in bits_list:
+        P = (8, bits, bits + 2)
+        # CPU: per-block streams, one thread and all threads
+        (cpu1, t_c1) = timed(lambda: [ox.compress_blocks(d, BLOCK, P, nthreads=1)[0] for d in datas])
+        (cpuN, t_cN) = timed(lambda: [ox.compress_blocks(d, BLOCK, P, nthreads=nthreads)[0] for d in datas])
+        want = [s for per in cpu1 for s in per]
+        (_, t_d1) = timed(lambda: [ox.decompress(s, P, cap=BLOCK + 16) for s in want])
+        # GPU, host-pointer call (best of 3)
+        (res, t_ge) = timed(lambda: rx.compress_blocks_v(datas, BLOCK, P), reps=3)
+        out, offs, st, first = res
+        got = [out[int(offs[i]): int(offs[i + 1])].tobytes() for i in range(len(offs) - 1)]
+        assert got == want, "batch streams differ from the restatement"
+        (dres, t_gd) = timed(lambda: rx.decompress_blocks_v(out, offs, [len(d) for d in datas], BLOCK, P), reps=3)
+        assert [g.tobytes() for g in dres[0]] == datas
+        # GPU, device resident: the _v_dev launches alone
+        lens = np.array([len(d) for d in datas], dtype=np.uint64)
+        doff = np.zeros(len(datas), dtype=np.uint64)
+        doff[1:] = np.cumsum((lens + 15) & ~np.uint64(15))[:-1]
+        total_in = int(doff[-1] + ((lens[-1] + 15) & ~np.uint64(15)))
+        tab = rx.block_table_v(doff, lens, BLOCK)
+        ne, nb = len(tab), len(offs) - 1   # table entries (idle lanes included), blocks
+        packed = np.zeros(total_in + 16, dtype=np.uint8)
+        for o, d in zip(doff, datas):
+            packed[int(o): int(o) + len(d)] = np.frombuffer(d, dtype=np.uint8)
+        cp = rx.Parameters(*P)._c()
+        d_in = torch.from_numpy(packed).cuda()
+        d_tab = torch.from_numpy(tab.view(np.uint8).copy()).cuda()
+        wsb = L.redux_encode_workspace_bytes(C.byref(cp), ne * BLOCK, BLOCK)
+        cap = nb * L.redux_encode_slot_bytes(C.byref(cp), BLOCK)
+        ws = torch.empty(wsb + 256, dtype=torch.uint8, device="cuda")
+        wsp = ws.data_ptr() + (-ws.data_ptr()) % 256
+        d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        d_offs = torch.zeros(nb + 1, dtype=torch.int64, device="cuda")
+        d_st = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        d_sum = torch.zeros(2, dtype=torch.int32, device="cuda")
+        strm = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def enc_dev():
+            d_sum.zero_()
+            r = L.redux_encode_blocks_v_dev(C.byref(cp), C.c_void_p(d_in.data_ptr()), total_in, C.c_void_p(d_tab.data_ptr()), ne, nb, BLOCK, 1,
+                                            C.c_void_p(d_out.data_ptr()), cap, C.c_void_p(d_offs.data_ptr()), C.c_void_p(d_st.data_ptr()),
+                                            C.c_void_p(d_sum.data_ptr()), C.c_void_p(wsp), wsb, strm)
+            assert r == 0
+        enc_dev()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); enc_dev(); e1.record()
+        torch.cuda.synchronize()
+        t_ke = e0.elapsed_time(e1) * 1e-3
+        assert d_sum.tolist() == [0, 0] and d_offs.cpu().numpy().astype(np.uint64).tolist() == offs.tolist()
+        dwsb = L.redux_decode_workspace_bytes(C.byref(cp), ne, BLOCK)
+        dws = torch.empty(dwsb + 256, dtype=torch.uint8, device="cuda")
+        dwsp = dws.data_ptr() + (-dws.data_ptr()) % 256
+        d_back = torch.zeros(total_in + 16, dtype=torch.uint8, device="cuda")
+        d_sz = torch.zeros(nb, dtype=torch.int32, device="cuda")
+
+        def dec_dev():
+            d_sum.zero_()
+            r = L.redux_decode_blocks_v_dev(C.byref(cp), C.c_void_p(d_out.data_ptr()), C.c_void_p(d_offs.data_ptr()), C.c_void_p(d_tab.data_ptr()),
+                                            ne, nb, BLOCK, 1, C.c_void_p(d_back.data_ptr()), total_in, C.c_void_p(d_sz.data_ptr()),
+                                            C.c_void_p(d_st.data_ptr()), C.c_void_p(d_sum.data_ptr()), C.c_void_p(dwsp), dwsb, strm)
+            assert r == 0
+        dec_dev()
+        torch.cuda.synchronize()
+        e0.record(); dec_dev(); e1.record()
+        torch.cuda.synchronize()
+        t_kd = e0.elapsed_time(e1) * 1e-3
+        assert d_sum.tolist() == [0, 0] and torch.equal(d_back[:total_in], d_in[:total_in])
+        print(f"  Bits: {bits}  blocks: {nb} in {(ne + 63) // 64} waves  Ratio: {n / len(out):.3f}")
+        print(f"    cpu, 1 thread      EncSpeed: {speed(n, t_c1):9.2f} MiB/s  DecSpeed: {speed(n, t_d1):9.2f} MiB/s")
+        print(f"    cpu, {nthreads:2d} threads    EncSpeed: {speed(n, t_cN):9.2f} MiB/s")
+        print(f"    gpu, host call     EncSpeed: {speed(n, t_ge):9.2f} MiB/s ({t_ge * 1e3:.2f} ms)  DecSpeed: {speed(n, t_gd):9.2f} MiB/s ({t_gd * 1e3:.2f} ms)")
+        print(f"    gpu, HBM resident  EncSpeed: {speed(n, t_ke):9.2f} MiB/s ({t_ke * 1e3:.2f} ms)  DecSpeed: {speed(n, t_kd):9.2f} MiB/s ({t_kd * 1e3:.2f} ms)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--corpora", default="artificial,calgary,canterbury,large,misc")
     ap.add_argument("--bits", default="14,22,30")
+    ap.add_argument("--batch", action="store_true", help="all files in one _v call (BASELINE.json configs[2] as ONE launch)")
     args = ap.parse_args()
     ox.lib()
+    if args.batch:
+        batch(args.corpora.split(","), [int(b) for b in args.bits.split(",")])
+        return
     rx.compress_blocks(b"warm", BLOCK, (8, 30, 32))
     print("# columns per file: OrigSize, then for cpu / lane / blocks: CompSize, Ratio, EncSpeed, DecSpeed (MiB/s)")
     for corpus in args.corpora.split(","):
