@@ -11,6 +11,7 @@
 //   redux::compress(istream, ostream, model) -> (u64,u64)   src/lib.rs:102
 //   redux::decompress(istream, ostream, model)              src/lib.rs:113
 //   redux::hip::compress_blocks / decompress_blocks         the block API the GPU path adds
+//   redux::hip::compress_blocks_v / decompress_blocks_v     many independent inputs in one launch (tests/corpora.rs:32-85)
 //
 // Every stream byte is produced by the gfx950 kernels; there is no CPU coder in this header.
 #pragma once
@@ -149,6 +150,58 @@ inline std::vector<std::uint8_t> decompress_blocks(const Blocks &streams, std::u
     if (sizes)
         *sizes = sz;
     return out;
+}
+
+// Many independent inputs in ONE launch (the reference's corpus harness codes file by file, tests/corpora.rs:32-85):
+// every input is cut into blocks on its own; first[i] is the number of input i's first block (inputs.size() + 1 entries).
+struct BlocksV {
+    Blocks                     blocks;
+    std::vector<std::uint64_t> first;
+};
+inline BlocksV compress_blocks_v(const std::vector<std::vector<std::uint8_t>> &inputs, std::uint32_t block_size,
+                                 const model::Parameters &p)
+{
+    const redux_params cp = p.c_abi();
+    check(redux_device_supports(&cp));
+    if (block_size == 0 || inputs.empty())
+        throw Error::from_status(REDUX_INVALID_INPUT);
+    std::vector<std::uint64_t> off(inputs.size()), len(inputs.size());
+    std::vector<std::uint8_t>  flat;
+    BlocksV                    r;
+    r.first.assign(inputs.size() + 1, 0);
+    for (std::size_t i = 0; i < inputs.size(); i++) {
+        off[i] = flat.size();
+        len[i] = inputs[i].size();
+        flat.insert(flat.end(), inputs[i].begin(), inputs[i].end());
+        r.first[i + 1] = r.first[i] + redux_block_count(len[i], block_size);
+    }
+    const std::uint64_t nb = redux_block_count_v(len.data(), len.size(), block_size);
+    r.blocks.data.resize(nb * redux_encode_slot_bytes(&cp, block_size));
+    r.blocks.offsets.resize(nb + 1);
+    check(redux_encode_blocks_v(&cp, flat.data(), off.data(), len.data(), len.size(), block_size, r.blocks.data.data(),
+                                r.blocks.data.size(), r.blocks.offsets.data(), nullptr));
+    r.blocks.data.resize(r.blocks.offsets[nb]);
+    return r;
+}
+inline std::vector<std::vector<std::uint8_t>> decompress_blocks_v(const Blocks &streams, const std::vector<std::uint64_t> &lengths,
+                                                                  std::uint32_t block_size, const model::Parameters &p)
+{
+    const redux_params cp = p.c_abi();
+    check(redux_device_supports(&cp));
+    if (block_size == 0 || lengths.empty() || streams.offsets.empty() ||
+        redux_block_count_v(lengths.data(), lengths.size(), block_size) + 1 != streams.offsets.size())
+        throw Error::from_status(REDUX_INVALID_INPUT);
+    std::vector<std::uint64_t> off(lengths.size(), 0);
+    for (std::size_t i = 1; i < lengths.size(); i++)
+        off[i] = off[i - 1] + lengths[i - 1];
+    std::vector<std::uint8_t>  out(off.back() + lengths.back() + 1);
+    std::vector<std::uint32_t> sz(streams.offsets.size() - 1);
+    check(redux_decode_blocks_v(&cp, streams.data.data(), streams.offsets.data(), out.data(), off.data(), lengths.data(),
+                                lengths.size(), block_size, sz.data(), nullptr));
+    std::vector<std::vector<std::uint8_t>> r(lengths.size());
+    for (std::size_t i = 0; i < lengths.size(); i++)
+        r[i].assign(out.begin() + off[i], out.begin() + off[i] + lengths[i]);
+    return r;
 }
 
 } // namespace hip

@@ -40,6 +40,14 @@ extern "C" {
     fn redux_decode_blocks(p: *const ReduxParams, input: *const u8, in_offsets: *const u64,
                            nblocks: u64, block_size: u32, out: *mut u8, out_cap: u64,
                            out_sizes: *mut u32, block_status: *mut i32) -> c_int;
+    fn redux_block_count_v(in_len: *const u64, ninputs: u64, block_size: u32) -> u64;
+    fn redux_encode_slot_bytes(p: *const ReduxParams, block_size: u32) -> u64;
+    fn redux_encode_blocks_v(p: *const ReduxParams, input: *const u8, in_off: *const u64, in_len: *const u64,
+                             ninputs: u64, block_size: u32, out: *mut u8, out_cap: u64,
+                             out_offsets: *mut u64, block_status: *mut i32) -> c_int;
+    fn redux_decode_blocks_v(p: *const ReduxParams, input: *const u8, in_offsets: *const u64, out: *mut u8,
+                             out_off: *const u64, out_len: *const u64, ninputs: u64, block_size: u32,
+                             out_sizes: *mut u32, block_status: *mut i32) -> c_int;
     fn redux_compress(p: *const ReduxParams, input: *const u8, in_len: u64, out: *mut u8,
                       out_cap: u64, bytes_in: *mut u64, bytes_out: *mut u64) -> c_int;
     fn redux_decompress(p: *const ReduxParams, input: *const u8, in_len: u64, out: *mut u8,
@@ -117,6 +125,65 @@ pub fn decompress_blocks(streams: &[u8], offsets: &[u64], block_size: u32, p: &P
         try!(status(redux_decode_blocks(&cp, streams.as_ptr(), offsets.as_ptr(), nb as u64, block_size,
                                         out.as_mut_ptr(), out.len() as u64, sizes.as_mut_ptr(), ptr::null_mut())));
         Ok((out, sizes))
+    }
+}
+
+/// Many independent inputs in ONE launch -- what the reference's corpus harness does file by file
+/// (tests/corpora.rs:32-85).  Every input is cut into blocks of `block_size` on its own (ragged tail per
+/// input, an empty input is one empty block); blocks are numbered input by input.  Returns the dense
+/// streams, `nblocks + 1` offsets and, per input, the number of its first block (`inputs.len() + 1`
+/// entries).  Block streams equal those of `compress_blocks` called once per input.
+pub fn compress_blocks_v(inputs: &[&[u8]], block_size: u32, p: &Parameters) -> Result<(Vec<u8>, Vec<u64>, Vec<u64>)> {
+    if block_size == 0 || inputs.is_empty() {
+        return Err(Error::InvalidInput);
+    }
+    let cp = c_params(p);
+    let lens: Vec<u64> = inputs.iter().map(|x| x.len() as u64).collect();
+    let mut offs_in = vec![0u64; inputs.len()];
+    let mut flat = Vec::with_capacity(lens.iter().sum::<u64>() as usize);
+    let mut first = vec![0u64; inputs.len() + 1];
+    for (i, x) in inputs.iter().enumerate() {
+        offs_in[i] = flat.len() as u64;
+        flat.extend_from_slice(x);
+        first[i + 1] = first[i] + unsafe { redux_block_count(lens[i], block_size) };
+    }
+    unsafe {
+        try!(status(redux_device_supports(&cp)));
+        let nb = redux_block_count_v(lens.as_ptr(), lens.len() as u64, block_size) as usize;
+        let cap = nb * redux_encode_slot_bytes(&cp, block_size) as usize;
+        let mut out = vec![0u8; cap];
+        let mut offs = vec![0u64; nb + 1];
+        try!(status(redux_encode_blocks_v(&cp, flat.as_ptr(), offs_in.as_ptr(), lens.as_ptr(), lens.len() as u64, block_size,
+                                          out.as_mut_ptr(), cap as u64, offs.as_mut_ptr(), ptr::null_mut())));
+        out.truncate(offs[nb] as usize);
+        Ok((out, offs, first))
+    }
+}
+
+/// Inverse of `compress_blocks_v`: `lengths[i]` is the decoded size of input `i`; returns the inputs back to back
+/// (input `i` at the sum of the lengths before it).
+pub fn decompress_blocks_v(streams: &[u8], offsets: &[u64], lengths: &[u64], block_size: u32, p: &Parameters) -> Result<Vec<u8>> {
+    if block_size == 0 || lengths.is_empty() || offsets.is_empty() || offsets[offsets.len() - 1] as usize > streams.len() {
+        return Err(Error::InvalidInput);
+    }
+    let cp = c_params(p);
+    let mut out_off = vec![0u64; lengths.len()];
+    for i in 1..lengths.len() {
+        out_off[i] = out_off[i - 1] + lengths[i - 1];
+    }
+    let total = (out_off[lengths.len() - 1] + lengths[lengths.len() - 1]) as usize;
+    unsafe {
+        try!(status(redux_device_supports(&cp)));
+        let nb = redux_block_count_v(lengths.as_ptr(), lengths.len() as u64, block_size) as usize;
+        if nb + 1 != offsets.len() {
+            return Err(Error::InvalidInput);
+        }
+        let mut out = vec![0u8; std::cmp::max(total, 1)];
+        let mut sizes = vec![0u32; nb];
+        try!(status(redux_decode_blocks_v(&cp, streams.as_ptr(), offsets.as_ptr(), out.as_mut_ptr(), out_off.as_ptr(),
+                                          lengths.as_ptr(), lengths.len() as u64, block_size, sizes.as_mut_ptr(), ptr::null_mut())));
+        out.truncate(total);
+        Ok(out)
     }
 }
 

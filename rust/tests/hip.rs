@@ -40,3 +40,26 @@ fn blocks_equal_per_block_compress() {
         assert_eq!(&back[b * 65536..][..sizes[b] as usize], chunk);
     }
 }
+
+// tests/corpora.rs:32-85 codes file by file; the batch call codes all of them in one launch and must give, block for
+// block, what compress_blocks gives for each input alone.
+#[test]
+fn batch_equals_per_input_calls() {
+    let p = Parameters::new(8, 30, 32).unwrap();
+    let a: Vec<u8> = (0..150_000u32).map(|i| (i.wrapping_mul(2654435761) >> 24) as u8).collect();
+    let b: Vec<u8> = Vec::new();
+    let c: Vec<u8> = (0..70_001u32).map(|i| (i % 7) as u8).collect();
+    let inputs: Vec<&[u8]> = vec![&a, &b, &c];
+    let (out, offs, first) = redux::hip::compress_blocks_v(&inputs, 65536, &p).unwrap();
+    for (i, x) in inputs.iter().enumerate() {
+        let (one, of1) = redux::hip::compress_blocks(x, 65536, &p).unwrap();
+        for k in 0..of1.len() - 1 {
+            let g = first[i] as usize + k;
+            assert_eq!(&out[offs[g] as usize..offs[g + 1] as usize], &one[of1[k] as usize..of1[k + 1] as usize]);
+        }
+    }
+    let lens: Vec<u64> = inputs.iter().map(|x| x.len() as u64).collect();
+    let back = redux::hip::decompress_blocks_v(&out, &offs, &lens, 65536, &p).unwrap();
+    assert_eq!(&back[..a.len()], &a[..]);
+    assert_eq!(&back[a.len()..], &c[..]);
+}

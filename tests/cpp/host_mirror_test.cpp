@@ -65,6 +65,27 @@ int main(int argc, char **argv)
             REQUIRE(total == in.size());
             std::printf("bits %d: %zu -> %zu bytes\n", bits, in.size(), b.data.size());
         }
+        // the same file three times over, cut at odd places, through the batch call: block for block what the per-input
+        // call gives, and back
+        Parameters q = Parameters::make(8, 30, 32);
+        std::vector<std::vector<std::uint8_t>> parts;
+        parts.emplace_back(in.begin(), in.begin() + in.size() / 3);
+        parts.emplace_back();
+        parts.emplace_back(in.begin() + in.size() / 3, in.end());
+        parts.emplace_back(in.begin(), in.begin() + 1);
+        hip::BlocksV v = hip::compress_blocks_v(parts, 65536, q);
+        REQUIRE(v.first.back() + 1 == v.blocks.offsets.size());
+        for (std::size_t i = 0; i < parts.size(); i++) {
+            hip::Blocks one = hip::compress_blocks(parts[i].data(), parts[i].size(), 65536, q);
+            for (std::size_t b = 0; b + 1 < one.offsets.size(); b++) {
+                const std::uint64_t o0 = v.blocks.offsets[v.first[i] + b], o1 = v.blocks.offsets[v.first[i] + b + 1];
+                REQUIRE(o1 - o0 == one.offsets[b + 1] - one.offsets[b]);
+                REQUIRE(std::memcmp(v.blocks.data.data() + o0, one.data.data() + one.offsets[b], o1 - o0) == 0);
+            }
+        }
+        std::vector<std::uint64_t> lens;
+        for (auto &x : parts) lens.push_back(x.size());
+        REQUIRE(hip::decompress_blocks_v(v.blocks, lens, 65536, q) == parts);
     }
     // a truncated stream is Error::Eof (bitio/mod.rs:107)
     threw = false;
