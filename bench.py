@@ -15,8 +15,11 @@ Extra objects on the JSON line:
   roofline      dominant kernel (k_encode): algorithmic bytes = sum over blocks of
                 (bytes read + bytes written), taken from the offsets table, divided by the
                 kernel's mean duration measured with HIP events on the launch stream inside
-                the timed steps; peak = 8.0e12 B/s (MI355X HBM3E).  `traffic` is the
-                PMC-measured HBM bytes per launch when profiles/traffic.json holds it.
+                the timed steps; peak = 8.0e12 B/s (MI355X HBM3E).  `traffic` (PMC-measured HBM
+                bytes per launch) and `issue` (VALU instructions and cycles per coded symbol: the
+                kernel is bound by instruction issue, not by HBM) are borrowed from profiles/
+                traffic.json / issue.json -- only when the profile's source hash is the loaded
+                library's (roofline.source_hash); otherwise null and the reason.
   cpu_baseline  the CPU oracle (C restatement of the reference, kind "port") on a bounded
                 prefix of the same workload, on this box's host cores, rank 0 at N=1 only.
   decode        (rank 0, after the timed steps, not part of `value`) one timed pass of the
@@ -177,19 +180,37 @@ def main():
     # the kernel the library's dispatch picked for exactly these arguments (not an assumption)
     kname = _lib.lib().redux_encode_kernel_name(C.byref(cp), C.c_void_p(d_in.data_ptr()), n, BLOCK).decode()
     dname = _lib.lib().redux_decode_kernel_name(C.byref(cp), None, BLOCK).decode()
-    # `traffic` is not measured by this run: it is the PMC figure of a separate rocprofv3 --pmc pass
-    # of this same command (tools/prof_traffic.sh), kept per workload in profiles/traffic.json
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    # `traffic` and `issue` are not measured by this run: they are PMC figures of separate rocprofv3 --pmc passes of this
+    # same command (tools/prof.sh -> tools/profile_json.py), kept per workload in profiles/traffic.json and
+    # profiles/issue.json together with the source hash of the library that was profiled.  A figure is only borrowed
+    # when that hash equals the loaded library's: after any change to the kernels it reads null + the reason.
+    lib_hash = _lib.lib().redux_source_hash().decode()
+
+    def borrowed(fname, want):
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            return None, f"no profiles/{fname}"
         try:
-            tj = json.load(open(tpath))
-            for ent in tj.get("entries", [tj]):
-                if ent.get("workload") == args.workload and ent.get("blocks") == nblocks and ent.get("kernel", "k_encode_pair") in kname:
-                    traffic = ent.get("hbm_bytes_per_launch")
-                    traffic_src = ent.get("source", "profiles/traffic.json")
-        except Exception:
-            traffic = None
+            ents = json.load(open(path)).get("entries", [])
+        except Exception as e:  # noqa: BLE001
+            return None, f"profiles/{fname} unreadable: {e}"
+        for ent in ents:
+            if all(ent.get(k) == v for k, v in want.items()):
+                if ent.get("source_hash") != lib_hash:
+                    return None, (f"profiles/{fname} was measured on source hash {ent.get('source_hash')}, the loaded library is "
+                                  f"{lib_hash}: re-run tools/prof.sh + tools/profile_json.py")
+                return ent, ent.get("source", f"profiles/{fname}")
+        return None, f"profiles/{fname} has no entry for {want}"
+
+    tent, traffic_src = borrowed("traffic.json", {"workload": args.workload, "blocks": nblocks})
+    traffic = tent.get("hbm_bytes_per_launch") if tent and tent.get("kernel", "") in kname else None
+    ient, issue_src = borrowed("issue.json", {"workload": args.workload, "blocks": nblocks, "kernel": kname.split(" (")[0]})
+    issue = ({k: ient[k] for k in ("valu_per_symbol", "lds_per_symbol", "salu_per_symbol", "cycles_per_symbol", "valu_issue_frac")}
+             if ient else None)
+    if issue is not None:
+        issue["source"] = issue_src
+    else:
+        issue = {"valu_per_symbol": None, "cycles_per_symbol": None, "valu_issue_frac": None, "source": issue_src}
     line = {
         "metric": "encode MB/s (whole node), per-block bitstream bit-exact",
         "value": round(value, 1),
@@ -222,6 +243,8 @@ def main():
             "frac": round(achieved * 1e9 / HBM_PEAK, 5),
             "traffic": traffic,
             "traffic_source": traffic_src,
+            "issue": issue,
+            "source_hash": lib_hash,
             "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_ms": round(kern_ms, 3),
         },
@@ -242,9 +265,14 @@ def main():
         torch.cuda.synchronize()
         assert d_sum.tolist() == [0, 0] and torch.equal(d_out, d_in), "decode(encode(x)) != x"
         dms = e0.elapsed_time(e1)
+        dent, dsrc = borrowed("issue.json", {"workload": args.workload, "blocks": nblocks, "kernel": dname.split(" (")[0]})
+        dissue = ({k: dent[k] for k in ("valu_per_symbol", "lds_per_symbol", "salu_per_symbol", "cycles_per_symbol", "valu_issue_frac")}
+                  if dent else {"valu_per_symbol": None, "cycles_per_symbol": None, "valu_issue_frac": None})
+        dissue["source"] = dsrc
         line["decode"] = {"kernel": dname, "ms": round(dms, 3),
                           "MBps": round(n / (dms * 1e-3) / 1e6, 1),
-                          "algorithmic_GBps": round(algo_bytes / (dms * 1e-3) / 1e9, 2), "roundtrip_equal": True}
+                          "algorithmic_GBps": round(algo_bytes / (dms * 1e-3) / 1e9, 2),
+                          "frac": round(algo_bytes / (dms * 1e-3) / HBM_PEAK, 5), "issue": dissue, "roundtrip_equal": True}
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import cbind as ox

@@ -238,6 +238,9 @@ int redux_static_decode_blocks_dev(const redux_params *p, const uint32_t *cum, c
 
 /* Library / build identification: "redux_hip <version> gfx950". */
 const char *redux_version(void);
+/* sha256 (first 16 hex digits) of the kernel sources + this header the library was built from ("unknown" when the
+ * build did not say): a profile records it, and a harness borrows a profiled figure only for the same sources. */
+const char *redux_source_hash(void);
 
 /* Which kernel redux_encode_slots_dev / redux_decode_blocks_dev launch for these arguments (the
  * same decision function the launch code uses; d_in / d_out only contribute their alignment).  A static

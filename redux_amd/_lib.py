@@ -24,6 +24,7 @@ _U32 = C.c_uint32
 # name -> (restype, argtypes): exactly the declarations of include/redux_hip.h
 SIGNATURES = {
     "redux_version": (C.c_char_p, []),
+    "redux_source_hash": (C.c_char_p, []),
     "redux_encode_kernel_name": (C.c_char_p, [_PP, _V, _U64, _U32]),
     "redux_decode_kernel_name": (C.c_char_p, [_PP, _V, _U32]),
     "redux_debug_rcp_check": (C.c_int, [_U64, _U64, C.POINTER(C.c_double)]),

@@ -17,13 +17,25 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and the C header, in a fixed order: what redux_source_hash()
+    returns for a library built from them.  Profiles record it, and bench.py only borrows a profiled figure (HBM traffic,
+    instruction counts) when the library it loaded was built from the same sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(os.path.basename(d).encode() + b"\0")
+        h.update(open(os.path.join(CSRC, d), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_lib(force=False, verbose=False):
     """Cross-compiles for gfx950 (works without a GPU).  Returns the .so path."""
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           '-DREDUX_SOURCE_HASH="%s"' % source_hash(), "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -304,7 +304,12 @@ using namespace redux;
 
 extern "C" {
 
-const char *redux_version(void) { return "redux_hip 0.2.0 gfx950"; }
+const char *redux_version(void) { return "redux_hip 0.3.0 gfx950"; }
+
+#ifndef REDUX_SOURCE_HASH
+#define REDUX_SOURCE_HASH "unknown"
+#endif
+const char *redux_source_hash(void) { return REDUX_SOURCE_HASH; }
 
 const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size)
 {

@@ -6,3 +6,4 @@ ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --workload ${W
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- python3 $ARGS > $OUT/pmc3.log 2>&1 || true
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc4 -- python3 $ARGS > $OUT/pmc4.log 2>&1 || true
 python3 tools/pmc_summary.py $OUT
+python3 tools/profile_json.py --encode $OUT --workload ${WORKLOAD:-iid}

@@ -1,14 +1,17 @@
 #!/bin/bash
 # Round-end measurement batch (GPU box): parity tests, bench lines, side measurements, rocprofv3 summaries.
-# Usage: tools/round_end.sh <tag>   -> gpurun_out/final_<tag>/...
+# Usage: tools/round_end.sh <tag>   -> gpurun_out/final_<tag>/... and gpurun_out/profiles_json/{traffic,issue}.json
 TAG=${1:-x}; OUT=gpurun_out/final_$TAG; mkdir -p $OUT
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/tests_gpu.log 2>&1; tail -2 $OUT/tests_gpu.log
+timeout -k 10 600 bash tools/prof.sh $TAG > $OUT/prof.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/prof_$TAG k_encode_pair > $OUT/prof_summary.txt 2>&1
+python3 tools/profile_json.py --encode gpurun_out/prof_$TAG --workload iid >> $OUT/prof.log 2>&1
+timeout -k 10 400 bash tools/prof_decode.sh dec_$TAG > $OUT/prof_decode.txt 2>&1
+python3 tools/profile_json.py --decode gpurun_out/prof_dec_$TAG --workload iid >> $OUT/prof.log 2>&1
+WORKLOAD=zipf timeout -k 10 400 bash tools/prof_traffic.sh zipf_$TAG > $OUT/prof_traffic_zipf.txt 2>&1
+cp $(ls -t gpurun_out/prof_$TAG/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+# the bench lines last: they borrow the figures the passes above just wrote (same library, same source hash)
 timeout -k 10 300 python bench.py --steps 10 --warmup 10 > $OUT/bench_iid.log 2>&1 && tail -1 $OUT/bench_iid.log
 timeout -k 10 300 python bench.py --steps 10 --warmup 10 --workload zipf --no-cpu-baseline > $OUT/bench_zipf.log 2>&1 && tail -1 $OUT/bench_zipf.log
 timeout -k 10 300 python tools/measure_extra.py > $OUT/extra.log 2>&1 && tail -1 $OUT/extra.log
-timeout -k 10 600 bash tools/prof.sh $TAG > $OUT/prof.log 2>&1
-python3 tools/pmc_summary.py gpurun_out/prof_$TAG k_encode_pair > $OUT/prof_summary.txt 2>&1
-timeout -k 10 400 bash tools/prof_decode.sh dec_$TAG > $OUT/prof_decode.txt 2>&1
-WORKLOAD=zipf timeout -k 10 400 bash tools/prof_traffic.sh zipf_$TAG > $OUT/prof_traffic_zipf.txt 2>&1
-cp $(ls -t gpurun_out/prof_$TAG/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 echo done
