@@ -53,7 +53,7 @@ typedef const __attribute__((address_space(4))) double *rc_ptr; // forces scalar
 // --------------------------------------------------------------------------------------
 // The masks finish() multiplies the node pairs with, one 16-byte row per value 0..256: (v * 0x8001 >> 2j) & 0x10001,
 // j = 0..3.  A byte s uses row s and row s + 1 (row 256 is all zero: the derived node 256 is added separately).
-// 4 KiB, read through the vector L1 by the pair kernel's model wave (REDUX_MASK_TABLE).
+// 4 KiB, read through the vector L1 by the pair kernel's model wave.
 struct MaskTable {
     uint32_t v[257 * 4];
     constexpr MaskTable() : v{}
@@ -300,8 +300,7 @@ __device__ __forceinline__ uint32_t scale_div(uint32_t R1, double Y, uint32_t f,
 // Encoder lane state.  low and ~high are kept LEFT-ALIGNED in 32 bits (value << sh, high
 // padded with ones, sh = 32 - code_bits), which makes renormalisation independent of
 // code_bits.  Output goes through a 64-bit accumulator; completed 32-bit groups are big-endian
-// (MSB-first stream, bitio/mod.rs:148-181), staged four at a time and stored at wave-uniform
-// base + 32-bit offset.  Stores that would pass `limit` are dropped but still counted, so an
+// (MSB-first stream, bitio/mod.rs:148-181) and stored at wave-uniform base + 32-bit offset.  Stores that would pass `limit` are dropped but still counted, so an
 // overflowing block ends with off > limit and is reported, never written out of bounds.
 // --------------------------------------------------------------------------------------
 struct EncState {
@@ -310,21 +309,16 @@ struct EncState {
     uint32_t nb;   // bits waiting in acc (< 32 between symbols)
     uint32_t off;  // byte offset of the next dword from the wave's uniform base
     uint64_t acc;  // newest bit at bit 0
-    uint4    q;    // the last four completed dwords, newest in .w: the staging area of a 16-byte store
 };
 
 __device__ __forceinline__ void enc_init(EncState &S, uint32_t off0) // codec.rs:28-36
 {
     S.low = 0; S.ihigh = 0; S.pend = 0; S.nb = 0; S.off = off0; S.acc = 0;
-    S.q = make_uint4(0, 0, 0, 0);
 }
 
-// A completed 32-bit group (already big-endian).  Default: stored at once (4 bytes per lane).
-// -DREDUX_STORE_X4: groups are staged in registers and leave as ONE aligned 16-byte store when
-// the fourth dword of a 16-byte group completes -- a quarter of the L2 write requests, and
-// WRITE_SIZE drops from 7.5e6 to 5.9e6 KiB per 4 GiB pass (L2 forwards every partial line
-// write at 32-byte granularity), at 6 % more kernel time; not the default because the kernel
-// is VALU-bound and the partial writes merge in the Infinity Cache.
+// A completed 32-bit group is stored at once, 4 bytes per lane.  (Staging four of them for one 16-byte store was built in
+// round 1: a quarter of the L2 write requests, WRITE_SIZE 7.5e6 -> 5.9e6 KiB per 4 GiB pass with linear slots, at 6 % more
+// kernel time -- the kernel is bound by instruction issue.  Row-major group areas took the write traffic to 1.00 x.)
 // `off` is always the byte offset of the NEXT dword; slots start 16-byte aligned.
 // ST: distance between a lane's consecutive dwords: 4 in a linear slot; 256 in a ROW-major group
 // area, where row r holds dword r of the group's 64 lanes (see Geometry in redux_hip.hip).
@@ -344,32 +338,9 @@ __device__ __forceinline__ uint32_t stream_dword(uint32_t w) // w: the next 32 s
 template <bool CHECKED, int ST = 4>
 __device__ __forceinline__ void emit_dword(EncState &S, uint32_t w, uint8_t *wbase, uint32_t limit)
 {
-#ifndef REDUX_STORE_X4 // default: one 4-byte store per completed group
     if (!CHECKED || S.off + stride_of<ST> <= limit)
         *reinterpret_cast<uint32_t *>(wbase + S.off) = w;
     S.off += stride_of<ST>;
-#else
-    static_assert(ST == 4, "staged 16-byte stores need linear slots");
-    S.q = make_uint4(S.q.y, S.q.z, S.q.w, w); // shift in place: the quad is stored as it stands
-    if ((S.off & 12u) == 12u && (!CHECKED || S.off + 4 <= limit))
-        *reinterpret_cast<uint4 *>(wbase + (S.off - 12u)) = S.q;
-    S.off += 4;
-#endif
-}
-
-// the 0..3 staged dwords of an incomplete group (end of a block)
-__device__ __forceinline__ void flush_staged(EncState &S, uint8_t *wbase, uint32_t limit)
-{
-#ifndef REDUX_STORE_X4
-    return;
-#endif
-    const uint32_t g = (S.off >> 2) & 3u;
-    if (g >= 3 && S.off - 12u + 4 <= limit)
-        *reinterpret_cast<uint32_t *>(wbase + (S.off - 12u)) = S.q.y;
-    if (g >= 2 && S.off - 8u + 4 <= limit)
-        *reinterpret_cast<uint32_t *>(wbase + (S.off - 8u)) = S.q.z;
-    if (g >= 1 && S.off - 4u + 4 <= limit)
-        *reinterpret_cast<uint32_t *>(wbase + (S.off - 4u)) = S.q.w;
 }
 
 template <int ST = 4>
@@ -481,14 +452,9 @@ __device__ __forceinline__ void encode_symbol_fast(EncState &S, uint32_t lo, uin
         asm("v_bfm_b32 %0, %1, %2" : "=v"(run) : "v"(Pz), "v"(k - 1u));
         S.acc = (S.acc << m) | (topk + run);
         const uint32_t nb = S.nb + m;
-#ifndef REDUX_STORE_X4
         if (nb >= 32) // the only predicated instruction group: shift, byte swap, store
             *reinterpret_cast<uint32_t *>(wbase + S.off) = __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u)));
         S.off += (nb >> 3) & 4u; // nb < 64: +4 exactly when a group completed
-#else
-        if (nb >= 32)
-            emit_dword<false>(S, __builtin_bswap32((uint32_t)(S.acc >> (nb - 32u))), wbase, 0);
-#endif
         S.nb = nb & 31u;
     } else { // some lane has a pending run too long for one append: careful path for all
         const uint32_t kk = k;
@@ -581,17 +547,9 @@ __device__ __forceinline__ uint32_t encode_symbol_spec(EncState &S, SpecCarry &C
     // stored bits off again (a lane that raised the flag has garbage here; everything stays bounded)
     const uint32_t nb = C.nbm + m;
     if ((int32_t)nb >= 0) { // one exec-masked region: shift, byte swap, store, advance
-#ifndef REDUX_STORE_X4
-#ifdef REDUX_NO_STORE // timing experiment only (output invalid): what the stream stores cost
-        asm volatile("" ::"v"(stream_dword<ST>((uint32_t)(S.acc >> (nb & 63u)))), "v"(S.off));
-#else
         *reinterpret_cast<uint32_t *>(wbase + S.off) = stream_dword<ST>((uint32_t)(S.acc >> (nb & 63u)));
-#endif
         // in place: as plain C++ the sum lands in a new register and a v_mov merges it after the region
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(S.off) : "i"(stride_of<ST>) : "memory");
-#else
-        emit_dword<false, ST>(S, stream_dword<ST>((uint32_t)(S.acc >> (nb & 63u))), wbase, 0);
-#endif
     }
     C.nbm = nb | 0xFFFFFFE0u;
     return m; // the caller raises the flag if any m of the half exceeds 32
@@ -613,7 +571,6 @@ __device__ __forceinline__ uint32_t encode_finish(EncState &S, uint32_t shifts, 
         if (rest > 0)
             put_bits<ST>(S, (S.low << 1) >> (32 - rest), rest, wbase, limit);
     }
-    flush_staged(S, wbase, limit);
     const uint32_t nbytes = (S.nb + 7) >> 3;
     const uint64_t tail   = S.nb ? (S.acc << (64 - S.nb)) : 0; // left-align, zero padding
     for (uint32_t i = 0; i < nbytes; i++) // nbytes <= 4: inside one dword in either layout

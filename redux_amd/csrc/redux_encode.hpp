@@ -264,34 +264,10 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
 constexpr uint32_t kRingSlots = 8;                               // symbols per hand-off
 constexpr uint32_t kRingBytes = 2 * kRingSlots * 64 * 8;         // two halves of uint2[8][64]
 
-#ifdef REDUX_STAMPS
-// Diagnostic build only (never timed, never shipped): every ring barrier is bracketed by
-// s_memtime; lane 0 of each wave accumulates {last stamp, cycles between barriers, cycles
-// inside barriers, count} in the tree's unused row 0 (LDS bytes 0..63) and the kernel copies
-// them to the spare slot at exit.  The barrier drains lgkmcnt anyway, so the stamps do not
-// change what the waves overlap.
-typedef __attribute__((address_space(3))) unsigned long long *lds64p;
-__device__ __forceinline__ void pair_barrier()
-{
-    unsigned long long t0, t1;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(t0), "=&s"(t1)::"memory");
-    if ((threadIdx.x & 63) == 0) {
-        lds64p a = (lds64p)(uintptr_t)((threadIdx.x >> 6) * 32);
-        const unsigned long long prev = a[0];
-        if (prev)
-            a[1] += t0 - prev;
-        a[2] += t1 - t0;
-        a[0] = t1;
-        a[3] += 1;
-    }
-}
-#else
 __device__ __forceinline__ void pair_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-#endif
 
 // Input path of the model wave: every lane reads its own block one whole 128-byte line at a
 // time (eight 16-byte loads issued back to back), so each line crosses the L2 <-> fabric
@@ -300,7 +276,7 @@ __device__ __forceinline__ void pair_barrier()
 // WRITE_SIZE drops 38 % as well (less L2 pollution).  c[] is the current line, n[] the next
 // one, already in flight; the chunk index is wave-uniform (the lanes advance in lock-step),
 // so pop() is a scalar switch.  Costs 2.8 % of kernel time (profiles/r01_traffic_matrix.txt);
-// -DREDUX_NO_LINE_QUEUE restores the 16-byte prefetch for A/B runs.
+// (16 bytes per visit: 2.8 % faster, 2.4-3.2 x the traffic).
 struct ChunkQueue {
     const uint8_t *base; // wave-uniform
     uint32_t       soff; // this lane's block offset
@@ -354,85 +330,31 @@ struct ChunkQueue {
     }
 };
 
-#ifndef REDUX_KEEP8
-#define REDUX_KEEP8 1
-#endif
-#ifndef REDUX_MODEL_PRIO
-#define REDUX_MODEL_PRIO 3
-#endif
-// 1 (default since round 2): the pair kernel writes ROW-major group areas -- row r = dword r of the group's 64 lanes --
-// so that the lanes of a wave, whose dword counts stay within one or two of each other, fill whole 128-byte lines
-// within a few symbols (L2 <-> fabric write traffic 1.0 x the stream instead of 4.1 x), and k_compact_rows gathers
-// them.  0: linear slots (one padded slot per block, 4-byte stores 64 lines apart) and k_compact, for A/B runs.
-#ifndef REDUX_ROWS
-#define REDUX_ROWS 1
-#endif
-#ifndef REDUX_PAIR_SWAP // 1: the pair kernel leaves the byte swap of every stream dword to the compaction (kSwapped, redux_coder.hpp)
-#if defined(REDUX_CODER_BRANCHY) || defined(REDUX_STORE_X4)
-#define REDUX_PAIR_SWAP 0
-#else
-#define REDUX_PAIR_SWAP 1
-#endif
-#endif
-constexpr int kPairStride = (REDUX_ROWS ? 256 : 4) | (REDUX_PAIR_SWAP ? kSwapped : 0);
-#ifndef REDUX_MODEL_DEPTH
-#define REDUX_MODEL_DEPTH 1
-#endif
-#ifndef REDUX_TOP_REG // 1: the model wave keeps node 128 (level 7) in a register while the model adapts
-#define REDUX_TOP_REG 1
-#endif
-// 1: the dot-product masks of finish() come from k_mask_table, loaded REDUX_MASK_AHEAD symbols ahead (14 VALU
-// instructions per symbol become two 16-byte loads); 0: computed, for A/B runs.
-#ifndef REDUX_MASK_TABLE
-#define REDUX_MASK_TABLE 1
-#endif
-#ifndef REDUX_MASK_AHEAD
-#define REDUX_MASK_AHEAD 8
-#endif
-#ifndef REDUX_ONE_WAIT
-#define REDUX_ONE_WAIT 1
-#endif
-#ifndef REDUX_PERM_ADDENDS
-#define REDUX_PERM_ADDENDS 1
-#endif
-#ifndef REDUX_MASK_BUFFER
-#define REDUX_MASK_BUFFER REDUX_PERM_ADDENDS
-#endif
-// 1: the ring holds the (low, high) pairs of two consecutive symbols side by side (16 bytes per lane), written by one
-// ds_write_b128 per two symbols and read by one ds_read_b128; 0: one 8-byte entry per symbol.
-#ifndef REDUX_RING_PAIRS
-#define REDUX_RING_PAIRS 1
-#endif
+// The pair kernel writes ROW-major group areas -- row r = dword r of the group's 64 lanes -- so that the lanes of a wave,
+// whose dword counts stay within one or two of each other on iid bytes, fill whole 128-byte lines within a few symbols
+// (L2 <-> fabric write traffic 1.0 x the stream instead of 4.1 x with one padded slot per block), and k_compact_rows
+// gathers them.
+constexpr int kPairStride = 256 | kSwapped; // row-major group areas, dwords left in accumulator order (redux_coder.hpp)
+// The dot-product masks of finish() come from k_mask_table, loaded kMaskAhead symbols ahead (14 VALU instructions per
+// symbol became two 16-byte loads).  The ring holds the (low, high) pairs of two consecutive symbols side by side (16 bytes
+// per lane), written by one ds_write_b128 per two symbols and read by one ds_read_b128.
 __device__ __forceinline__ uint32_t ring_at(uint32_t i, uint32_t lane) // index of symbol i's entry, in uint2 units
 {
-    return REDUX_RING_PAIRS ? (i >> 1) * 128u + lane * 2u + (i & 1u) : i * 64u + lane;
+    return (i >> 1) * 128u + lane * 2u + (i & 1u);
 }
-// 1: the coder wave (which has the slack) pulls every input line into the L2 a line-time before the model wave asks for
-// it, so that the model wave's in-order vector loads are never queued behind an HBM miss: 1.3 % faster (10.57 -> 10.44
-// ms), but the lines do not stay in the L2 until they are used and FETCH_SIZE doubles (2.11e6 -> 4.18e6 KiB per 4 GiB;
-// 3.62e6 with the touch half a line later).  Not the default: the read side stays at 1.00 x the input.
-#ifndef REDUX_CODER_TOUCH
-#define REDUX_CODER_TOUCH 0
-#endif
-#ifndef REDUX_TOUCH_AT // where in its 128-symbol line the coder wave touches the line after next (a multiple of 16)
-#define REDUX_TOUCH_AT 0
-#endif
-#ifndef REDUX_MASK_SDWA
-#define REDUX_MASK_SDWA 1
-#endif
-static_assert(REDUX_MASK_AHEAD == 4 || REDUX_MASK_AHEAD == 8, "prime() covers these");
-static_assert(16 % REDUX_MASK_AHEAD == 0, "slot i % AHEAD must mean the same in every chunk");
+// (Tried: the coder wave, which has the slack, pulling every input line into the L2 a line-time before the model wave asks
+// for it: 1.3 % faster, but the lines do not stay in the L2 until they are used and FETCH_SIZE doubles.  Not kept: the read
+// side stays at 1.00 x the input.)
+constexpr int kMaskAhead = 8; // symbols between a mask row's load and its use (4: 11.25 ms, 8: 11.01 ms when it was introduced)
+static_assert(kMaskAhead == 4 || kMaskAhead == 8, "prime() covers these");
+static_assert(16 % kMaskAhead == 0, "slot i % AHEAD must mean the same in every chunk");
 struct MaskPipe {
-    uint4    s[REDUX_MASK_AHEAD], m[REDUX_MASK_AHEAD];
+    uint4    s[kMaskAhead], m[kMaskAhead];
     uint32_t four; // the constant 4 in a VGPR: SDWA has no inline constants on gfx9
-#if REDUX_MASK_BUFFER
     __amdgpu_buffer_rsrc_t rsrc; // k_mask_table as a raw buffer (257 rows of 16 bytes)
-#endif
     __device__ __forceinline__ void init()
     {
-#if REDUX_MASK_BUFFER
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(k_mask_table.v), 0, sizeof k_mask_table.v, 0x00027000);
-#endif
         four = 4;
         asm volatile("" : "+v"(four));
     }
@@ -441,7 +363,6 @@ struct MaskPipe {
     __device__ __forceinline__ uint32_t row_of(int K, uint32_t w) const // K: a constant once the caller's loop is unrolled
     {
         uint32_t off;
-#if REDUX_MASK_SDWA
         if (K == 0)
             asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(four), "v"(w));
         else if (K == 1)
@@ -450,32 +371,18 @@ struct MaskPipe {
             asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(four), "v"(w));
         else
             asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(four), "v"(w));
-#else
-        off = ((w >> (8 * K)) & 0xFFu) << 4;
-#endif
         return off;
     }
     __device__ __forceinline__ void load(int slot, uint32_t row) // row = 16 * symbol
     {
         const char *e = reinterpret_cast<const char *>(k_mask_table.v) + row;
-#if REDUX_MASK_BUFFER
         // (as buffer loads: a plain 16-byte load whose dwords are used in two places -- addends and sums -- is split by
         // the compiler into a 12- and a 4-byte gather, and the texture-address path pays per gather; the intrinsic stays whole)
         (void)e;
         const auto r0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row, 0, 0), r1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row + 16u, 0, 0);
         s[slot] = make_uint4(r0[0], r0[1], r0[2], r0[3]);
         m[slot] = make_uint4(r1[0], r1[1], r1[2], r1[3]);
-#else
-        s[slot] = *reinterpret_cast<const uint4 *>(e);
-        m[slot] = *reinterpret_cast<const uint4 *>(e + 16);
-#endif
         const uint32_t sym = row >> 4; // (only the probe below uses it)
-#ifdef REDUX_PROBE_VMEM // experiment: N more 16-byte gathers per symbol, into accumulation registers nothing else uses
-        if (REDUX_PROBE_VMEM >= 1)
-            asm volatile("global_load_dwordx4 a[0:3], %0, %1" ::"v"((sym << 4) ^ 16u), "s"(k_mask_table.v) : "a0", "a1", "a2", "a3", "memory");
-        if (REDUX_PROBE_VMEM >= 2)
-            asm volatile("global_load_dwordx4 a[4:7], %0, %1" ::"v"((sym << 4) ^ 32u), "s"(k_mask_table.v) : "a4", "a5", "a6", "a7", "memory");
-#endif
     }
     // the first AHEAD symbols of a chunk (entering a run of model_chunk calls)
     __device__ __forceinline__ void prime(const uint4 cur)
@@ -483,9 +390,9 @@ struct MaskPipe {
         init();
         const uint32_t w[2] = {cur.x, cur.y};
         load(0, row_of(0, w[0])); load(1, row_of(1, w[0])); load(2, row_of(2, w[0])); load(3, row_of(3, w[0]));
-        if (REDUX_MASK_AHEAD == 8) {
-            load(4 % REDUX_MASK_AHEAD, row_of(0, w[1])); load(5 % REDUX_MASK_AHEAD, row_of(1, w[1]));
-            load(6 % REDUX_MASK_AHEAD, row_of(2, w[1])); load(7 % REDUX_MASK_AHEAD, row_of(3, w[1]));
+        if (kMaskAhead == 8) {
+            load(4 % kMaskAhead, row_of(0, w[1])); load(5 % kMaskAhead, row_of(1, w[1]));
+            load(6 % kMaskAhead, row_of(2, w[1])); load(7 % kMaskAhead, row_of(3, w[1]));
         }
     }
 };
@@ -494,21 +401,21 @@ template <bool UPD>
 __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, uint32_t lane, const uint4 cur, const uint4 nxt,
                                             MaskPipe &mp, uint32_t p, uint32_t nfreeze, uint32_t *top = nullptr)
 {
-    constexpr int kInFlight = (UPD && REDUX_TOP_REG) ? 7 : 8; // LDS ops of one symbol
+    constexpr int kInFlight = UPD ? 7 : 8; // LDS ops of one symbol (node 128 of an adapting model lives in a register)
     const uint32_t w[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
     auto sym = [&](int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; };
     // (Keeping the symbols the mask loads extracted, 8 registers, instead of extracting them again here: one VALU
     // instruction fewer per symbol and 0.9 % slower, profiles/r02_masktable/ab.txt.)
     // software pipeline: symbol i+1's LDS ops are in flight while symbol i's sums are formed
     // (depths 2 and 3 measured no faster in round 1 and slower with the mask table, 11.37 / 11.72 against 11.02 ms: LDS latency is not what the model wave waits for)
-    constexpr int D = REDUX_MODEL_DEPTH;
+    constexpr int D = 1;
     Tree<true>::Nodes q[D + 1];
-    uint2             held = make_uint2(0, 0); // REDUX_RING_PAIRS: the even symbol of a pair, until the odd one is done
-    // (REDUX_PERM_ADDENDS: the adapting model takes its addends from the symbol's masks, Tree::issue_masked)
-    constexpr bool kMasked = REDUX_PERM_ADDENDS && REDUX_MASK_TABLE && UPD && REDUX_TOP_REG && D == 1;
+    uint2             held = make_uint2(0, 0); // the even symbol of a pair, until the odd one is done
+    // (the adapting model takes its addends from the symbol's masks, Tree::issue_masked)
+    constexpr bool kMasked = UPD && D == 1;
 #pragma unroll
     for (int d = 0; d < D; d++)
-        q[d] = kMasked ? T.issue_masked(sym(d), mp.s[d % REDUX_MASK_AHEAD], top) : T.template issue<UPD>(sym(d), true, top);
+        q[d] = kMasked ? T.issue_masked(sym(d), mp.s[d % kMaskAhead], top) : T.template issue<UPD>(sym(d), true, top);
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const uint32_t s   = sym(i);
@@ -516,9 +423,9 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
         // At the hand-over in the middle of the chunk the next symbol's eight LDS ops are issued
         // AFTER this symbol's ring write and stay in flight across the barrier (LDS ops of a wave
         // complete in order, so lgkmcnt <= 8 means the ring half is written).
-        const bool late = REDUX_KEEP8 && i == 7;
+        const bool late = i == 7;
         if (i + D < 16 && !late) {
-            q[D] = kMasked ? T.issue_masked(sym(i + D), mp.s[(i + D) % REDUX_MASK_AHEAD], top) : T.template issue<UPD>(sym(i + D), true, top);
+            q[D] = kMasked ? T.issue_masked(sym(i + D), mp.s[(i + D) % kMaskAhead], top) : T.template issue<UPD>(sym(i + D), true, top);
             __builtin_amdgcn_sched_barrier(0);
         }
         // One hand-placed s_waitcnt for all seven node values of symbol i -- the ring write of i - 1 and the seven
@@ -529,43 +436,26 @@ __device__ __forceinline__ void model_chunk(const Tree<true> &T, uint2 *ring, ui
         // it and drops its own; where the count is different (chunk start, around the mid-chunk barrier) it is left
         // to the compiler.  finish_tab() uses the masks loaded second first, so one vmcnt wait covers both loads.
         uint32_t lo, hi;
-#if REDUX_ONE_WAIT
-        if (D == 1 && i + D < 16 && !late && i != 8 && i != 0 && REDUX_MASK_TABLE && kInFlight == 7)
+        if (D == 1 && i + D < 16 && !late && i != 8 && i != 0 && kInFlight == 7)
         {
-            if (REDUX_RING_PAIRS && (i & 1)) // (no ring write between the atomics of i and of i + 1)
+            if (i & 1) // (no ring write between the atomics of i and of i + 1)
                 __builtin_amdgcn_s_waitcnt(0xC00F | 0x70 | (7 << 8));
             else
                 __builtin_amdgcn_s_waitcnt(0xC00F | 0x70 | (8 << 8)); // vmcnt and expcnt fields all ones = no wait
         }
-#endif
-#if REDUX_MASK_TABLE
-        T.finish_tab(s, nup, q[0], mp.s[i % REDUX_MASK_AHEAD], mp.m[i % REDUX_MASK_AHEAD], lo, hi);
-        mp.load(i % REDUX_MASK_AHEAD, mp.row_of((i + REDUX_MASK_AHEAD) & 3, w[(i + REDUX_MASK_AHEAD) >> 2])); // (the last ones are the next chunk's)
-#else
-        T.finish(s, nup, q[0], lo, hi);
-#endif
-#ifdef REDUX_PROBE_MODEL // experiment: N extra independent VALU instructions per symbol in the model wave
-#pragma unroll
-        for (int k = 0; k < REDUX_PROBE_MODEL; k++) {
-            uint32_t dummy = lo;
-            asm volatile("v_add_u32 %0, %0, %1" : "+v"(dummy) : "v"(hi));
-        }
-#endif
+        T.finish_tab(s, nup, q[0], mp.s[i % kMaskAhead], mp.m[i % kMaskAhead], lo, hi);
+        mp.load(i % kMaskAhead, mp.row_of((i + kMaskAhead) & 3, w[(i + kMaskAhead) >> 2])); // (the last ones are the next chunk's)
         // (lo and hi come out of v_dot2, and gfx950 wants three wait states between a dot result and an
         // LDS instruction reading it: the compiler puts an s_nop here.  Filling the gap instead -- the next symbol's
         // address preparation pinned there in round 1, the two mask loads ordered there with sched_group_barrier
         // in round 2 -- removes the s_nop and is no faster (10.64 against 10.53 ms for the latter).)
-#if REDUX_RING_PAIRS
         if (i & 1) {
             *reinterpret_cast<uint4 *>(ring + ring_at(i - 1, lane)) = make_uint4(held.x, held.y, lo, hi);
         } else
             held = make_uint2(lo, hi);
-#else
-        ring[i * 64 + lane] = make_uint2(lo, hi);
-#endif
         if (late) {
             __builtin_amdgcn_sched_barrier(0);
-            q[D] = kMasked ? T.issue_masked(sym(i + D), mp.s[(i + D) % REDUX_MASK_AHEAD], top) : T.template issue<UPD>(sym(i + D), true, top);
+            q[D] = kMasked ? T.issue_masked(sym(i + D), mp.s[(i + D) % kMaskAhead], top) : T.template issue<UPD>(sym(i + D), true, top);
             if (kInFlight == 7)
                 asm volatile("s_waitcnt lgkmcnt(7)\n\ts_barrier" ::: "memory");
             else
@@ -593,18 +483,12 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
     for (int h = 0; h < 2; h++) {
         pair_barrier();
         uint2 lh[8]; // the whole half at once: one LDS round trip per 8 symbols
-#if REDUX_RING_PAIRS
 #pragma unroll
         for (int i = 0; i < 8; i += 2) {
             const uint4 two = *reinterpret_cast<const uint4 *>(ring + ring_at(h * 8 + i, lane));
             lh[i]     = make_uint2(two.x, two.y);
             lh[i + 1] = make_uint2(two.z, two.w);
         }
-#else
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            lh[i] = ring[(h * 8 + i) * 64 + lane];
-#endif
         double rn[8];
         if (MODE == 0) {
             uint32_t zero; // opaque 0 that "depends" on the ring data: pins the loads behind the LDS wait
@@ -614,15 +498,6 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
             for (int i = 0; i < 8; i++)
                 rn[i] = nb[i];
         }
-#ifdef REDUX_CODER_BRANCHY // the older form: a ballot branch inside every symbol
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t nup = MODE == 0 ? p + h * 8 + i : nfreeze;
-            uint32_t       hi  = lh[i].y;
-            asm volatile("" : "+v"(hi)); // keeps ISel from turning (u64 >> 32) -> f64 into a 64-bit conversion (+1 v_add_f64)
-            encode_symbol_fast<FIXUP, CB32>(S, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
-        }
-#else
         // Eight symbols straight-line; the rare symbol whose pending run needs more than one
         // 32-bit append only raises a flag, and the half is then redone from the saved state
         // with the general encode_symbol (no per-symbol branch, no merge of two state versions).
@@ -639,13 +514,6 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
             const uint32_t hi = lh[i].y;
             const uint32_t m = encode_symbol_spec<FIXUP, CB32, kPairStride>(S, C, lh[i].x, hi, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, wdst);
             mx               = m > mx ? m : mx;
-#ifdef REDUX_PROBE_CODER // experiment: N extra independent VALU instructions per symbol in the coder wave
-#pragma unroll
-            for (int k = 0; k < REDUX_PROBE_CODER; k++) {
-                uint32_t dummy = lh[i].x;
-                asm volatile("v_add_u32 %0, %0, %1" : "+v"(dummy) : "v"(hi));
-            }
-#endif
         }
         spec_end(S, C);
         const uint64_t bad = __builtin_amdgcn_ballot_w64(mx > 32u);
@@ -657,7 +525,6 @@ __device__ __forceinline__ void coder_chunk(EncState &S, const uint2 *ring, uint
                 encode_symbol<FIXUP, kPairStride>(S, lh[i].x, lh[i].y, 257u + nup, MODE == 0 ? r[i] : rc[nfreeze], sh, false, wdst, 0xFFFFFFFFu);
             }
         }
-#endif
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 8; i++)
@@ -687,13 +554,10 @@ __device__ __forceinline__ void coder_chunk_checked(EncState &S, const uint2 *ri
 // alternates them perfectly, launched right after another kernel it puts two first-waves on
 // some SIMDs (profiles/r01_final/placement_census.txt) -- two model waves at half speed each,
 // which the whole lock-step kernel then waits for (0.5-3 ms of 13).  So the roles are not tied
-// to the wave index: they are booked per CU at run time (REDUX_CLAIMS, below).
+// to the wave index: they are booked per CU at run time (below).
 // (Tried instead: whole-CU workgroups of eight waves = four pairs, waves w and w+4 sharing a
 // SIMD.  Placement is then perfect by construction, but the eight-wave s_barrier couples the
 // four pairs and the kernel takes 14.05 ms against 12.8 ms.)
-#ifndef REDUX_CLAIMS
-#define REDUX_CLAIMS 1
-#endif
 constexpr uint32_t kClaimWords = 2048; // (xcc:3, se:3, sh:1, cu:4) -> one word per CU
 constexpr uint32_t kPairDwords = Tree<true>::kDwords + kRingBytes / 4;
 
@@ -711,7 +575,6 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
         reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
     uint32_t role = w8;
     uint2   *ring = reinterpret_cast<uint2 *>(lds + Tree<true>::kDwords);
-#if REDUX_CLAIMS
     // claims[cu] counts the model waves (bits 4s..4s+3) and coder waves (bits 16+4s..) booked on
     // SIMD s of that CU.  A workgroup whose waves sit on SIMDs (s0, s1) books (model, coder) =
     // (s0, s1), or (s1, s0) when that collides with fewer roles already booked, and returns its
@@ -747,9 +610,6 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
         role ^= __builtin_amdgcn_readfirstlane(book[2]);
         claim_delta = book[3];
     }
-#else
-    __syncthreads();
-#endif
     const uint32_t wave = role; // 0 = model, 1 = coder
     Tree<true> T;
     T.init(lds, lane);
@@ -757,18 +617,12 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
     const uint8_t *wsrc;
     const EncLane  EL    = enc_lane(a, blk0, blk, lane, live, wsrc);
     const uint32_t len   = EL.len, soff = EL.soff;
-#if REDUX_ROWS
     // row-major group area: dword r of lane l at wdst + 256 r + 4 l (dead lanes own a column too).
     // The areas are an ODD number of 128-byte lines apart: all groups write row r at about the
     // same time, and an even stride folds those lines onto a fraction of the L2 sets.
     uint8_t       *wdst  = a.slots + (uint64_t)blockIdx.x * (64 * a.slot_bytes + 128);
     const uint32_t off0  = lane * 4u;
     const uint32_t limit = off0 + (a.slot_cap / 4u) * 256u;
-#else
-    uint8_t       *wdst  = a.slots + blk0 * a.slot_bytes;
-    const uint32_t off0  = live ? lane * (uint32_t)a.slot_bytes : (uint32_t)(a.nblocks - blk0) * (uint32_t)a.slot_bytes;
-    const uint32_t limit = off0 + a.slot_cap;
-#endif
 
     const uint32_t minlen  = __builtin_amdgcn_readfirstlane(wave_min(live ? len : 0xFFFFFFFFu));
     const uint32_t maxlen  = __builtin_amdgcn_readfirstlane(wave_max(live ? len : 0u));
@@ -792,43 +646,23 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
         // The model wave is the pair's critical path (it works ~590 cycles per symbol, the coder wave
         // ~430 and then waits at the ring barrier), but the SIMD's arbiter serves the two waves
         // round-robin: raising the model wave's issue priority lets it run at nearly the lone-wave
-        // rate while the coder wave fills the gaps.  15.96 -> 14.0 ms (REDUX_MODEL_PRIO=0 for the A/B).
-        __builtin_amdgcn_s_setprio(REDUX_MODEL_PRIO);
+        // rate while the coder wave fills the gaps.  15.96 -> 14.0 ms.
+        __builtin_amdgcn_s_setprio(3);
         if (main_end) {
             uint32_t p = 0;
-#ifndef REDUX_NO_LINE_QUEUE
             ChunkQueue Q;
             Q.init(wsrc, soff, main_end);
 #define NEXT_CHUNK() Q.pop()
-#else
-            uint4    held = *reinterpret_cast<const uint4 *>(wsrc + soff);
-            uint32_t held_at = 0;
-            auto  next_chunk = [&]() {
-                const uint4 r = held;
-                held_at += 16;
-                if (held_at < main_end)
-                    held = *reinterpret_cast<const uint4 *>(wsrc + soff + held_at);
-                return r;
-            };
-#define NEXT_CHUNK() next_chunk()
-#endif
             // cur = the chunk at p, nxt the one after it (model_chunk loads masks a few symbols ahead, across the chunk boundary)
             uint4    cur = NEXT_CHUNK(), nxt;
             MaskPipe mp;
             mp.prime(cur);
-#if REDUX_TOP_REG
             uint32_t top = 0; // node 128 in this lane's half, as the LDS dword would hold it
             for (; p < a_end; p += 16, cur = nxt) {
                 nxt = NEXT_CHUNK(); // (one past the end at the last turn: the queue re-reads its last chunk)
                 model_chunk<true>(T, ring, lane, cur, nxt, mp, p, nfreeze, &top);
             }
             T.add(T.A[7], top); // from here on (freeze-crossing chunk, frozen chunks, the coder wave's tail) the tree is read from LDS
-#else
-            for (; p < a_end; p += 16, cur = nxt) {
-                nxt = NEXT_CHUNK();
-                model_chunk<true>(T, ring, lane, cur, nxt, mp, p, nfreeze);
-            }
-#endif
             for (; p < m_end; p += 16) { // rolled: the update stops in the middle of this chunk
                 for (uint32_t i = 0; i < 16; i++) {
                     const uint32_t q   = p + i;
@@ -850,24 +684,10 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
         }
     } else {
         // ---------------- coder wave ----------------
-#ifdef REDUX_CODER_PRIO
-        __builtin_amdgcn_s_setprio(REDUX_CODER_PRIO);
-#endif
         uint32_t p = 0;
         double   r[8];      // reciprocals of the first eight symbols of chunk r_at
         uint32_t r_at = ~0u;
-#if REDUX_CODER_TOUCH
-        uint32_t touched = 0; // destination of the touch loads: never read, live to the end so that nothing else is put there
-#endif
         for (; p < main_end; p += 16) {
-#if REDUX_CODER_TOUCH
-            // The model wave's vector loads return in order: a mask-table load issued behind an input-line load that
-            // misses to HBM is not usable before that line has arrived.  This wave has the slack (it waits ~60 cycles
-            // per symbol at the ring), so it pulls every input line into the L2 one line-time before the model wave
-            // asks for it: one 4-byte load per lane and 128 symbols, into a register nobody reads.
-            if ((p & 127u) == REDUX_TOUCH_AT && (p & ~127u) + 256u + 4u <= main_end)
-                asm volatile("global_load_dword %0, %1, %2" : "+v"(touched) : "v"(soff + (p & ~127u) + 256u), "s"(wsrc) : "memory");
-#endif
             if (__builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit) || (p >= a_end && p < m_end))
                 coder_chunk_checked<FIXUP>(S, ring, lane, p, nfreeze, rc, sh, wdst, limit);
             else if (p < a_end) {
@@ -881,22 +701,8 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
             } else
                 coder_chunk<FIXUP, 1, CB32>(S, ring, lane, p, nfreeze, rc, sh, wdst, r);
         }
-#if REDUX_CODER_TOUCH
-        asm volatile("" ::"v"(touched));
-#endif
     }
     __syncthreads(); // the model wave's last updates are in LDS before the tail reads the tree
-#ifdef REDUX_STAMPS
-    if (lane == 0) {
-        lds64p st = (lds64p)(uintptr_t)(w8 * 32);
-        unsigned long long *dstp = reinterpret_cast<unsigned long long *>(a.slots + a.nblocks * a.slot_bytes) + (blockIdx.x * 2 + wave) * 4;
-        uint32_t hwid, xcc; // where this wave ran: (xcc, se, sh, cu, simd) -- the pair needs one model and one coder wave per SIMD
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        dstp[0] = st[1]; dstp[1] = st[2]; dstp[2] = st[3];
-        dstp[3] = wave | ((unsigned long long)(hwid & 0xFFFFu) << 8) | ((unsigned long long)(xcc & 0xFu) << 24);
-    }
-#endif
     if (wave == 0)
         return;
 
@@ -916,7 +722,6 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
             a.status[EL.ob] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
         }
     }
-#if REDUX_CLAIMS
     if (lane == 0) { // waves do not migrate: the same CU as at the start
         uint32_t hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -924,7 +729,6 @@ __global__ void __launch_bounds__(128) k_encode_pair(EncArgs a)
         __hip_atomic_fetch_sub(a.claims + (((xcc & 7u) << 8) | ((hwid >> 8) & 0xFFu)), claim_delta, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
-#endif
 }
 
 } // namespace redux

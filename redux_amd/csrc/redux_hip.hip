@@ -478,8 +478,8 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
     const EncKernel which = pick_encode_kernel(g, p, a.aligned16 != 0, block_size);
     // what the pair kernel leaves in the slots (CompactArgs::mode): byte 0x01 -> row-major group
     // areas, 0x02 -> linear slots whose dwords are byte-reversed
-    if ((which == EncKernel::PairCb32 || which == EncKernel::Pair) && (REDUX_ROWS || REDUX_PAIR_SWAP))
-        HIP_TRY(hipMemsetAsync(ws + g.off_mode, (REDUX_ROWS ? 1 : 0) | (REDUX_PAIR_SWAP ? 2 : 0), 4, s));
+    if (which == EncKernel::PairCb32 || which == EncKernel::Pair)
+        HIP_TRY(hipMemsetAsync(ws + g.off_mode, 1 | 2, 4, s));
     switch (which) {
     case EncKernel::PairCb32: k_encode_pair<false, true><<<grid, 128, 0, s>>>(a); break;
     case EncKernel::Pair: k_encode_pair<false, false><<<grid, 128, 0, s>>>(a); break;
@@ -536,13 +536,11 @@ static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *
     ca.cap_rows   = (uint32_t)(g.slot_bytes / 4);
     ca.table      = d_table;
     k_compact<<<(uint32_t)g.nblocks, 256, 0, s>>>(ca);
-#if REDUX_ROWS // the mode word decides on the device which of the two does the work
     if (!g.any && g.u16) {
         const uint32_t tiles = (ca.cap_rows + kTileRows - 1) / kTileRows + 1;
         const uint32_t groups = (uint32_t)((g.nblocks + 63) / 64);
-        k_compact_rows<<<(REDUX_ROWS_XCD ? (groups + 7) / 8 * 8 : groups) * tiles, 256, 0, s>>>(ca);
+        k_compact_rows<<<(groups + 7) / 8 * 8 * tiles, 256, 0, s>>>(ca); // (whole sets of 8 groups: k_compact_rows' XCD-aware mapping)
     }
-#endif
     HIP_TRY(hipGetLastError());
     return REDUX_OK;
 }
@@ -1051,7 +1049,7 @@ int redux_static_decode_blocks_dev(const redux_params *p, const uint32_t *cum, c
         la.rc           = a.rc;
         la.tab          = a.tab;
         const bool solo = grid <= 4u * cu_count(); // at most one wave per SIMD: keep the dispatcher from doubling them up
-        if (REDUX_STATIC_LUT && cum[kStaticEntries - 1] <= 65536u) { // get_symbol by direct lookup
+        if (cum[kStaticEntries - 1] <= 65536u) { // get_symbol by direct lookup
             if (solo) {
                 if (p->code_bits == 32)
                     k_decode_static_lut<true, 4><<<(grid + 3) / 4, 256, 0, s>>>(la);

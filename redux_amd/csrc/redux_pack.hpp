@@ -4,13 +4,13 @@
 //   k_scan_sizes     sizes -> offsets (exclusive scan, one workgroup) + status summary;
 //                    k_scan_sizes_coalesced for whole chunks of 4096 blocks (the headline shape)
 //   k_compact        slot b [0, size_b) -> out + offsets[b], 16-byte stores with byte realignment
-//   k_compact_rows   the same from row-major group areas (what k_encode_pair leaves; -DREDUX_ROWS=0 builds: never)
+//   k_compact_rows   the same from row-major group areas (what k_encode_pair leaves)
 //
 // Included by redux_hip.hip (one translation unit).
 #pragma once
 
 #include "redux_coder.hpp"
-#include "redux_encode.hpp" // REDUX_ROWS
+#include "redux_encode.hpp"
 
 #include "../../include/redux_hip.h"
 
@@ -46,12 +46,9 @@ struct ScanArgs {
     uint64_t        nblocks;
 };
 
-#ifndef REDUX_SCAN_COALESCED
-#define REDUX_SCAN_COALESCED 1
-#endif
 static inline bool scan_is_coalesced(const ScanArgs &a)
 {
-    return REDUX_SCAN_COALESCED && a.nblocks % 4096 == 0 && a.nblocks / 4096 <= 16 &&
+    return a.nblocks % 4096 == 0 && a.nblocks / 4096 <= 16 &&
            ((((uintptr_t)a.sizes) | ((uintptr_t)a.status) | ((uintptr_t)a.offsets)) & 15) == 0;
 }
 
@@ -321,16 +318,13 @@ __global__ void __launch_bounds__(256) k_compact(CompactArgs a)
         dst[done + tid] = src[(done + tid) ^ bx];
 }
 
-// Row-major group areas (REDUX_ROWS): row r of group g holds dword r of its 64 streams
+// Row-major group areas: row r of group g holds dword r of its 64 streams
 // (slots + g * 64 * slot_bytes + 256 r + 4 l).  One workgroup gathers a tile of 64 rows: the
 // rows are read whole (coalesced) into LDS, then every stream's 64 dwords of the tile leave as
 // one 256-byte run of ALIGNED dwords of the dense output: output dword j of a stream that starts
 // at byte offset sh (0..3) inside its first aligned dword is the byte-funnel of source dwords
 // j-1 and j.  Only a stream's first and last output dword can be partial: those go bytewise.
 constexpr uint32_t kTileRows = 64;
-#ifndef REDUX_ROWS_XCD
-#define REDUX_ROWS_XCD 1
-#endif
 __global__ void __launch_bounds__(256) k_compact_rows(CompactArgs a)
 {
     const uint32_t mode = *a.mode;
@@ -342,7 +336,6 @@ __global__ void __launch_bounds__(256) k_compact_rows(CompactArgs a)
     __shared__ uint32_t s_n[64], s_sh[64];
     __shared__ uint32_t s_maxj;
     const uint32_t tiles = (a.cap_rows + kTileRows - 1) / kTileRows + 1;
-#if REDUX_ROWS_XCD
     // XCD-aware mapping: workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  A
     // stream's consecutive 256-byte runs come from consecutive tiles of its group and share cache lines at their
     // ends: all tiles of a group go to ONE XCD (blockIdx = 8 * (8-group block * tiles + tile) + group's slot), so the
@@ -352,10 +345,6 @@ __global__ void __launch_bounds__(256) k_compact_rows(CompactArgs a)
     const uint32_t r0  = (y % tiles) * kTileRows;
     if (g * 64 >= a.nblocks)
         return;
-#else
-    const uint64_t g     = blockIdx.x / tiles;
-    const uint32_t r0    = (blockIdx.x % tiles) * kTileRows;
-#endif
     const uint32_t tid   = threadIdx.x;
     if (tid == 0)
         s_maxj = 0;

@@ -316,9 +316,6 @@ __global__ void __launch_bounds__(64) k_decode_static_lock(StaticLockArgs a)
     decode_lock_body<CB32, 1>(a.d, lds, a.tab.cum, a.rc);
 }
 
-#ifndef REDUX_STATIC_LUT // 0: the Fenwick descent (k_decode_static_lock) for every total below 2^17, for A/B runs
-#define REDUX_STATIC_LUT 1
-#endif
 // Totals up to 2^16: get_symbol by direct lookup (dec_search_lut).  WAVES waves share one 64 KiB byte table lut[v] =
 // symbol and the plain cumulative table; each has its own 8 KiB stream ring: 4 waves = 97 KiB, one workgroup and one wave
 // per SIMD on a CU (the headline shape: 1024 groups of 64 blocks), 8 waves = 129 KiB for grids beyond that.
