@@ -24,7 +24,8 @@
  *   - Thread-safe.  The `_dev` calls and the geometry helpers keep no state at all.  The
  *     host-pointer calls share ONE lazily created, mutex-guarded context per device (chunk slots
  *     in HBM, pinned staging, streams; grown on demand, never shrunk, freed by
- *     redux_host_release()): calls from several host threads are safe and run one after the other.
+ *     redux_host_release()): calls from several host threads are safe; two that use the same
+ *     context run one after the other, two on different devices run concurrently.
  *   - The `_dev` calls launch on HIP's CURRENT device; every pointer must belong to it.
  */
 #ifndef REDUX_HIP_H
@@ -150,6 +151,23 @@ int redux_compress(const redux_params *p, const uint8_t *in, uint64_t in_len, ui
                    uint64_t *bytes_in, uint64_t *bytes_out);
 int redux_decompress(const redux_params *p, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
                      uint64_t *bytes_in, uint64_t *bytes_out);
+
+/* Several GPUs behind the host-pointer calls.  By default a call runs on HIP's current device.
+ * redux_host_set_devices(ids, n) (n <= 16; n = 0: back to the default) makes every later
+ * redux_encode_blocks / redux_decode_blocks deal its chunks round-robin over n contexts, context i on
+ * device ids[i] -- chunk k goes to context k mod n -- each with its own streams, HBM slots and
+ * pinned staging, each fed over its own PCIe link by its own host threads; the data starts and ends
+ * in host memory, so the devices exchange nothing (no collective).  An id may appear more than once
+ * (two contexts on one device: what the one-GPU test box exercises).  The `_v` calls use context 0.
+ * Existing contexts are released by the call.  Returns INVALID_INPUT for an id that is not a device.
+ * redux_host_chunk_plan: the chunking such a call uses for nblocks blocks on ncontexts contexts
+ * (whole waves of 64 blocks per chunk); host arithmetic only.
+ * redux_host_set_chunk_bytes: overrides the chunk size limits (bytes of payload per chunk; 0, 0 = the
+ * defaults, 16 MiB .. 128 / 256 MiB): a harness uses it to drive many chunks through a small input. */
+int  redux_host_set_devices(const int32_t *device_ids, uint32_t n);
+int  redux_host_chunk_plan(uint64_t nblocks, uint32_t block_size, uint32_t ncontexts, int decode, uint64_t *chunk_blocks,
+                           uint64_t *nchunks);
+int  redux_host_set_chunk_bytes(uint64_t min_bytes, uint64_t max_bytes);
 
 /* Frees every per-device context of the host-pointer calls (they are rebuilt on the next call).
  * redux_host_allocations: hipMalloc + hipHostMalloc calls the contexts have made so far -- a

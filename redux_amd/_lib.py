@@ -47,6 +47,9 @@ SIGNATURES = {
     "redux_compress": (C.c_int, [_PP, _V, _U64, _V, _U64, C.POINTER(_U64), C.POINTER(_U64)]),
     "redux_decompress": (C.c_int, [_PP, _V, _U64, _V, _U64, C.POINTER(_U64), C.POINTER(_U64)]),
     "redux_host_release": (C.c_int, []),
+    "redux_host_set_devices": (C.c_int, [_V, _U32]),
+    "redux_host_chunk_plan": (C.c_int, [_U64, _U32, _U32, C.c_int, C.POINTER(_U64), C.POINTER(_U64)]),
+    "redux_host_set_chunk_bytes": (C.c_int, [_U64, _U64]),
     "redux_host_allocations": (_U64, []),
     "redux_host_trace": (_U64, [C.POINTER(C.c_double), _U64]),
     "redux_encode_blocks_dev": (C.c_int, [_PP, _V, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),

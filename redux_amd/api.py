@@ -176,6 +176,26 @@ def decompress_blocks(streams, offsets, block_size, params=(8, 30, 32), check=Tr
     return out, sizes, status
 
 
+# ---- several GPUs behind the host-pointer calls ------------------------------------------------
+def host_set_devices(device_ids):
+    """redux_host_set_devices: later compress_blocks / decompress_blocks calls deal their chunks round-robin over one
+    context per entry of device_ids (an id may repeat); [] = back to HIP's current device."""
+    ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+    _raise(_lib.lib().redux_host_set_devices(ids.ctypes.data if ids.size else None, int(ids.size)))
+
+
+def host_chunk_plan(nblocks, block_size, ncontexts=1, decode=False):
+    """(blocks per chunk, number of chunks) a host-pointer call uses; chunk k runs on context k % ncontexts."""
+    cb, nc = C.c_uint64(), C.c_uint64()
+    _raise(_lib.lib().redux_host_chunk_plan(nblocks, block_size, ncontexts, 1 if decode else 0, C.byref(cb), C.byref(nc)))
+    return cb.value, nc.value
+
+
+def host_set_chunk_bytes(min_bytes=0, max_bytes=0):
+    """Test hook: chunk size limits of the host-pointer pipeline (0, 0 = the defaults)."""
+    _raise(_lib.lib().redux_host_set_chunk_bytes(min_bytes, max_bytes))
+
+
 # ---- many independent inputs in one call (tests/corpora.rs:32-85 codes file by file) --------
 BLOCK_DTYPE = np.dtype([("offset", "<u8"), ("length", "<u4"), ("index", "<u4")])  # redux_block
 BLOCK_IDLE = 0xFFFFFFFF  # REDUX_BLOCK_IDLE

@@ -1081,6 +1081,27 @@ int redux_static_decode_blocks_dev(const redux_params *p, const uint32_t *cum, c
 
 int redux_host_release(void) { return host::ctx_release_all(); }
 
+int redux_host_set_devices(const int32_t *device_ids, uint32_t n) { return host::set_devices(device_ids, n); }
+
+int redux_host_set_chunk_bytes(uint64_t min_bytes, uint64_t max_bytes)
+{
+    if (max_bytes && max_bytes < min_bytes)
+        return REDUX_INVALID_INPUT;
+    host::g_chunk_min.store(min_bytes);
+    host::g_chunk_max.store(max_bytes);
+    return REDUX_OK;
+}
+
+int redux_host_chunk_plan(uint64_t nblocks, uint32_t block_size, uint32_t ncontexts, int decode, uint64_t *chunk_blocks,
+                          uint64_t *nchunks)
+{
+    if (nblocks == 0 || block_size == 0 || ncontexts == 0 || ncontexts > 16 || !chunk_blocks || !nchunks)
+        return REDUX_INVALID_INPUT;
+    *chunk_blocks = host::chunk_blocks_for(nblocks, block_size, decode ? host::kDecChunkMax : host::kEncChunkMax, ncontexts);
+    *nchunks      = (nblocks + *chunk_blocks - 1) / *chunk_blocks;
+    return REDUX_OK;
+}
+
 uint64_t redux_host_allocations(void)
 {
     uint64_t n = 0;

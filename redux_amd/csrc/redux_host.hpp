@@ -30,6 +30,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -309,128 +310,226 @@ static int drain_d2h(Ctx &c, uint8_t *dst, const void *d_src, uint64_t len)
     return REDUX_OK;
 }
 
-// blocks per chunk: whole 64-block waves; an eighth of the call (eight chunks in flight), within
-// [kChunkMin, chunk_max] bytes of payload
-static uint64_t chunk_blocks_for(uint64_t nblocks, uint32_t block_size, uint64_t chunk_max)
+// ---- which contexts a host-pointer call runs on ------------------------------------------------
+// Default: the context of HIP's current device (g_ctx[device id]).  redux_host_set_devices() installs a FLEET instead:
+// context i serves device fleet[i] -- ids may repeat, each entry is its own context with its own streams and buffers --
+// and every redux_encode_blocks / redux_decode_blocks call deals its chunks round-robin over all of them.  The data starts
+// and ends in host memory, so nothing is exchanged between devices: each context is fed over its own PCIe link.
+static std::mutex       g_fleet_mu;
+static std::vector<int> g_fleet;                                    // empty: current device only
+static std::atomic<uint64_t> g_chunk_min{0}, g_chunk_max{0};        // test hook (redux_host_set_chunk_bytes): 0 = the defaults
+
+static int contexts_for_call(std::vector<Ctx *> &out)
 {
-    uint64_t bytes = (nblocks * (uint64_t)block_size + kSlots - 1) / kSlots;
-    bytes = bytes < kChunkMin ? kChunkMin : bytes > chunk_max ? chunk_max : bytes;
+    std::lock_guard<std::mutex> l(g_fleet_mu);
+    if (g_fleet.empty()) {
+        Ctx *cp = nullptr;
+        int  rc = ctx_of_current_device(&cp);
+        if (rc != REDUX_OK)
+            return rc;
+        out.push_back(cp);
+        return REDUX_OK;
+    }
+    for (size_t i = 0; i < g_fleet.size(); i++) {
+        g_ctx[i].device = g_fleet[i];
+        out.push_back(&g_ctx[i]);
+    }
+    return REDUX_OK;
+}
+
+static int set_devices(const int32_t *ids, uint32_t n)
+{
+    if (n > 16 || (n && !ids))
+        return REDUX_INVALID_INPUT;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess)
+        return REDUX_IO_ERROR;
+    for (uint32_t i = 0; i < n; i++)
+        if (ids[i] < 0 || ids[i] >= count)
+            return REDUX_INVALID_INPUT;
+    ctx_release_all(); // contexts are bound to a device when they are built: start from none
+    std::lock_guard<std::mutex> l(g_fleet_mu);
+    g_fleet.assign(ids, ids + n);
+    return REDUX_OK;
+}
+
+// blocks per chunk: whole 64-block waves; an eighth of a context's share of the call (eight chunks in flight per
+// context), within [kChunkMin, chunk_max] bytes of payload
+static uint64_t chunk_blocks_for(uint64_t nblocks, uint32_t block_size, uint64_t chunk_max, size_t nctx)
+{
+    const uint64_t lo = g_chunk_min.load() ? g_chunk_min.load() : kChunkMin;
+    const uint64_t hi = g_chunk_max.load() ? g_chunk_max.load() : chunk_max;
+    uint64_t bytes = (nblocks * (uint64_t)block_size + kSlots * nctx - 1) / (kSlots * nctx);
+    bytes = bytes < lo ? lo : bytes > hi ? hi : bytes;
     uint64_t cb = (bytes + block_size - 1) / block_size;
     cb = (cb + 63) / 64 * 64;
     return cb < nblocks ? cb : nblocks;
 }
 
+// what the contexts of one call share
+struct Job {
+    std::mutex              m;
+    std::condition_variable cv;
+    bool                    abort = false;
+    int                     error = REDUX_OK;
+    uint64_t                bad_chunk = ~0ull; // first chunk (in block order) with a non-OK block, and that status
+    int                     bad_status = REDUX_OK;
+    // encode only: where a chunk's streams go in the dense output is known once every earlier chunk's size is
+    std::vector<uint64_t> total, prefix; // prefix[k] = sum of total[0..k): valid for k <= prefix_n
+    std::vector<char>     known;
+    uint64_t              prefix_n = 0;
+
+    void fail(int rc)
+    {
+        std::lock_guard<std::mutex> l(m);
+        if (error == REDUX_OK)
+            error = rc;
+        abort = true;
+        cv.notify_all();
+    }
+    void note_bad(uint64_t chunk, int st)
+    {
+        std::lock_guard<std::mutex> l(m);
+        if (chunk < bad_chunk) {
+            bad_chunk  = chunk;
+            bad_status = st;
+        }
+    }
+};
+
 // ================================================================================================
 // encode
 // ================================================================================================
-static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_len, uint32_t block_size, uint8_t *out,
-                         uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
-{
-    Ctx *cp = nullptr;
-    int  rc = ctx_of_current_device(&cp);
-    if (rc != REDUX_OK)
-        return rc;
-    Ctx &c = *cp;
-    std::lock_guard<std::mutex> lock(c.mu);
-    if ((rc = ctx_init_locked(c)) != REDUX_OK)
-        return rc;
+struct EncCall {
+    const redux_params *p;
+    const uint8_t      *in;
+    uint64_t            in_len;
+    uint32_t            block_size;
+    uint8_t            *out;
+    uint64_t            out_cap;
+    uint64_t           *out_offsets;
+    int32_t            *block_status;
+    uint64_t            nblocks, cb, nchunks, ws_bytes, bound, chunk_in;
+};
 
-    const uint64_t nblocks = redux_block_count(in_len, block_size);
-    const uint64_t cb      = chunk_blocks_for(nblocks, block_size, kEncChunkMax);
-    const uint64_t nchunks = (nblocks + cb - 1) / cb;
-    const uint64_t chunk_in = cb * (uint64_t)block_size; // bytes of a full chunk
-    const uint64_t ws_bytes = redux_encode_workspace_bytes(p, chunk_in < in_len ? chunk_in : in_len, block_size);
-    const uint64_t bound    = redux_encode_bound(p, chunk_in < in_len ? chunk_in : in_len, block_size);
-    const int      nslots   = (int)(nchunks < (uint64_t)kSlots ? nchunks : (uint64_t)kSlots);
+// the chunks first, first + stride, ... of the call on context c (the calling thread of the call holds c.mu)
+static void encode_on_ctx(Ctx &c, const EncCall &E, Job &J, uint64_t first, uint64_t stride)
+{
+    if (hipSetDevice(c.device) != hipSuccess)
+        return J.fail(REDUX_IO_ERROR);
+    int rc = ctx_init_locked(c);
+    if (rc != REDUX_OK)
+        return J.fail(rc);
+    const uint64_t mine = first < E.nchunks ? (E.nchunks - first + stride - 1) / stride : 0; // chunks of this context
+    const uint64_t first_len = E.chunk_in < E.in_len ? E.chunk_in : E.in_len;
+    const int      nslots = (int)(mine < (uint64_t)kSlots ? mine : (uint64_t)kSlots);
     for (int i = 0; i < nslots; i++) {
         Slot &s = c.slot[i];
-        if ((rc = grow_dev(c, s.d_in, (chunk_in < in_len ? chunk_in : in_len) + 16)) || (rc = grow_dev(c, s.d_ws, ws_bytes + 256)) ||
-            (rc = grow_dev(c, s.d_out, bound + 16)) || (rc = grow_dev(c, s.d_off, (cb + 1) * 8)) || (rc = grow_dev(c, s.d_st, cb * 4)) ||
-            (rc = grow_dev(c, s.d_sum, 8)) || (rc = grow_pinned(c, s.h_off, (cb + 1) * 8)) || (rc = grow_pinned(c, s.h_st, cb * 4)) ||
-            (rc = grow_pinned(c, s.h_sum, 8)))
-            return rc;
+        if ((rc = grow_dev(c, s.d_in, first_len + 16)) || (rc = grow_dev(c, s.d_ws, E.ws_bytes + 256)) || (rc = grow_dev(c, s.d_out, E.bound + 16)) ||
+            (rc = grow_dev(c, s.d_off, (E.cb + 1) * 8)) || (rc = grow_dev(c, s.d_st, E.cb * 4)) || (rc = grow_dev(c, s.d_sum, 8)) ||
+            (rc = grow_pinned(c, s.h_off, (E.cb + 1) * 8)) || (rc = grow_pinned(c, s.h_st, E.cb * 4)) || (rc = grow_pinned(c, s.h_sum, 8)))
+            return J.fail(rc);
     }
-
-    c.trace.assign(nchunks * 4, 0.0);
+    c.trace.assign(mine * 4, 0.0);
     c.t0 = now_s();
-    Handover H;
-    int      first_bad = REDUX_OK; // first non-OK per-block status, in block order (what the _dev summary reports)
-    // ---- drain thread: results of chunk k -> caller memory, in chunk order --------------------
+    Handover H; // between this context's issuing thread and its drain thread; j = ordinal of a chunk within this context
+    // ---- drain thread: results of chunk k -> caller memory -------------------------------------
     std::thread drain([&] {
         (void)hipSetDevice(c.device);
-        uint64_t base = 0;
-        for (uint64_t k = 0; k < nchunks; k++) {
+        for (uint64_t j = 0; j < mine; j++) {
+            const uint64_t k = first + j * stride;
             {
                 std::unique_lock<std::mutex> l(H.m);
-                H.cv.wait(l, [&] { return H.issued > k || H.abort; });
+                H.cv.wait(l, [&] { return H.issued > j || H.abort; });
                 if (H.abort)
                     return;
             }
-            Slot          &s  = c.slot[k % kSlots];
-            const uint64_t b0 = k * cb, nb = (b0 + cb <= nblocks ? cb : nblocks - b0);
+            Slot          &s  = c.slot[j % kSlots];
+            const uint64_t b0 = k * E.cb, nb = (b0 + E.cb <= E.nblocks ? E.cb : E.nblocks - b0);
             int            err = REDUX_OK;
-            hipStream_t st = c.stream[k % kStreams]; // idle once the chunk's event has fired
+            hipStream_t st = c.stream[j % kStreams]; // idle once the chunk's event has fired
             if (hipEventSynchronize(s.done) != hipSuccess ||
                 hipMemcpyAsync(s.h_off.p, s.d_off.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(s.h_sum.p, s.d_sum.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess)
                 err = REDUX_IO_ERROR;
-            c.trace[k * 4 + 2] = now_s() - c.t0;
+            c.trace[j * 4 + 2] = now_s() - c.t0;
             const uint64_t *ho    = (const uint64_t *)s.h_off.p;
             const uint64_t  total = err ? 0 : ho[nb];
-            const int32_t  *sum   = (const int32_t *)s.h_sum.p;
-            if (!err && first_bad == REDUX_OK && sum[0] != REDUX_OK)
-                first_bad = sum[0];
-            if (!err && base + total > out_cap)
+            uint64_t        base  = 0;
+            if (!err) {
+                if (((const int32_t *)s.h_sum.p)[0] != REDUX_OK)
+                    J.note_bad(k, ((const int32_t *)s.h_sum.p)[0]);
+                // publish this chunk's size, then wait for the sizes of all earlier chunks (other contexts' included)
+                std::unique_lock<std::mutex> l(J.m);
+                J.total[k] = total;
+                J.known[k] = 1;
+                while (J.prefix_n < E.nchunks && J.known[J.prefix_n]) {
+                    J.prefix[J.prefix_n + 1] = J.prefix[J.prefix_n] + J.total[J.prefix_n];
+                    J.prefix_n++;
+                }
+                J.cv.notify_all();
+                J.cv.wait(l, [&] { return J.abort || J.prefix_n >= k; });
+                if (J.abort)
+                    err = -1; // (another context failed: its error is the call's)
+                else
+                    base = J.prefix[k];
+            }
+            if (!err && base + total > E.out_cap)
                 err = REDUX_OUTPUT_TOO_SMALL;
             if (!err && total)
-                err = drain_d2h(c, out + base, s.d_out.p, total);
+                err = drain_d2h(c, E.out + base, s.d_out.p, total);
             if (!err) {
                 for (uint64_t i = 0; i <= nb; i++)
-                    out_offsets[b0 + i] = base + ho[i];
-                if (block_status)
-                    memcpy(block_status + b0, s.h_st.p, nb * 4);
-                base += total;
+                    E.out_offsets[b0 + i] = base + ho[i]; // (entry b0 + nb is written again, with the same value, by the next chunk)
+                if (E.block_status)
+                    memcpy(E.block_status + b0, s.h_st.p, nb * 4);
             }
-            c.trace[k * 4 + 3] = now_s() - c.t0;
+            c.trace[j * 4 + 3] = now_s() - c.t0;
+            if (err > 0)
+                J.fail(err);
             std::lock_guard<std::mutex> l(H.m);
-            if (err && H.error == REDUX_OK)
-                H.error = err;
-            H.drained = k + 1;
-            H.cv.notify_all();
-            if (err) {
+            H.drained = j + 1;
+            if (err)
                 H.abort = true;
+            H.cv.notify_all();
+            if (err)
                 return;
-            }
         }
     });
 
-    // ---- issuing side (this thread): stage, H2D, kernels, small D2H -----------------------------
+    // ---- issuing side (this thread): stage, H2D, kernels ----------------------------------------
     {
         CopyPool pool(kCopyThreads - 1);
         uint64_t piece_no = 0;
-        for (uint64_t k = 0; k < nchunks && rc == REDUX_OK; k++) {
+        for (uint64_t j = 0; j < mine; j++) {
+            const uint64_t k = first + j * stride;
             {
                 std::unique_lock<std::mutex> l(H.m); // the slot's previous chunk must be in the caller's memory
-                H.cv.wait(l, [&] { return H.abort || k < (uint64_t)kSlots || H.drained + kSlots > k; });
+                H.cv.wait(l, [&] { return H.abort || j < (uint64_t)kSlots || H.drained + kSlots > j; });
                 if (H.abort)
                     break;
             }
-            c.trace[k * 4 + 0] = now_s() - c.t0;
-            Slot          &s  = c.slot[k % kSlots];
-            hipStream_t    st = c.stream[k % kStreams];
-            const uint64_t b0 = k * cb, nb = (b0 + cb <= nblocks ? cb : nblocks - b0);
-            const uint64_t o0 = b0 * (uint64_t)block_size;
-            const uint64_t len = (o0 + nb * (uint64_t)block_size <= in_len) ? nb * (uint64_t)block_size : in_len - o0;
+            {
+                std::lock_guard<std::mutex> l(J.m);
+                if (J.abort)
+                    break;
+            }
+            c.trace[j * 4 + 0] = now_s() - c.t0;
+            Slot          &s  = c.slot[j % kSlots];
+            hipStream_t    st = c.stream[j % kStreams];
+            const uint64_t b0 = k * E.cb, nb = (b0 + E.cb <= E.nblocks ? E.cb : E.nblocks - b0);
+            const uint64_t o0 = b0 * (uint64_t)E.block_size;
+            const uint64_t len = (o0 + nb * (uint64_t)E.block_size <= E.in_len) ? nb * (uint64_t)E.block_size : E.in_len - o0;
             auto issue = [&]() -> int {
-                int r = stage_h2d(c, pool, piece_no, s.d_in.p, in + o0, len, st);
+                int r = stage_h2d(c, pool, piece_no, s.d_in.p, E.in + o0, len, st);
                 if (r != REDUX_OK)
                     return r;
                 HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
                 uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
-                r = redux_encode_blocks_dev(p, s.d_in.p, len, block_size, s.d_out.p, bound, s.d_off.p, s.d_st.p, s.d_sum.p, ws,
-                                            ws_bytes, st);
+                r = redux_encode_blocks_dev(E.p, s.d_in.p, len, E.block_size, s.d_out.p, E.bound, s.d_off.p, s.d_st.p, s.d_sum.p, ws,
+                                            E.ws_bytes, st);
                 if (r != REDUX_OK)
                     return r;
                 // (the small result arrays are fetched by the drain thread once the event has fired: a D2H
@@ -440,23 +539,68 @@ static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_l
                 return REDUX_OK;
             };
             rc = issue();
-            c.trace[k * 4 + 1] = now_s() - c.t0;
+            c.trace[j * 4 + 1] = now_s() - c.t0;
+            if (rc != REDUX_OK)
+                J.fail(rc);
             std::lock_guard<std::mutex> l(H.m);
-            if (rc != REDUX_OK) {
+            if (rc != REDUX_OK)
                 H.abort = true;
-                if (H.error == REDUX_OK)
-                    H.error = rc;
-            } else
-                H.issued = k + 1;
+            else
+                H.issued = j + 1;
+            H.cv.notify_all();
+            if (rc != REDUX_OK)
+                break;
+        }
+        {
+            std::lock_guard<std::mutex> l(H.m); // (left early because another context failed: release the drain thread)
+            if (H.issued < mine)
+                H.abort = true;
             H.cv.notify_all();
         }
     }
     drain.join();
     for (int i = 0; i < kStreams; i++) // nothing of this call stays in flight
         (void)hipStreamSynchronize(c.stream[i]);
-    if (H.error != REDUX_OK)
-        return H.error;
-    return first_bad;
+}
+
+static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_len, uint32_t block_size, uint8_t *out,
+                         uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
+{
+    std::vector<Ctx *> ctx;
+    int rc = contexts_for_call(ctx);
+    if (rc != REDUX_OK)
+        return rc;
+    std::vector<std::unique_lock<std::mutex>> locks; // (always taken in context order: two calls cannot deadlock)
+    for (Ctx *c : ctx)
+        locks.emplace_back(c->mu);
+    int caller_dev = -1;
+    (void)hipGetDevice(&caller_dev);
+
+    EncCall E;
+    E.p = p; E.in = in; E.in_len = in_len; E.block_size = block_size; E.out = out; E.out_cap = out_cap;
+    E.out_offsets = out_offsets; E.block_status = block_status;
+    E.nblocks  = redux_block_count(in_len, block_size);
+    E.cb       = chunk_blocks_for(E.nblocks, block_size, kEncChunkMax, ctx.size());
+    E.nchunks  = (E.nblocks + E.cb - 1) / E.cb;
+    E.chunk_in = E.cb * (uint64_t)block_size; // bytes of a full chunk
+    E.ws_bytes = redux_encode_workspace_bytes(p, E.chunk_in < in_len ? E.chunk_in : in_len, block_size);
+    E.bound    = redux_encode_bound(p, E.chunk_in < in_len ? E.chunk_in : in_len, block_size);
+    Job J;
+    J.total.assign(E.nchunks, 0);
+    J.known.assign(E.nchunks, 0);
+    J.prefix.assign(E.nchunks + 1, 0);
+    const uint64_t nctx = ctx.size() < E.nchunks ? ctx.size() : E.nchunks; // (a call of one chunk uses one context)
+    std::vector<std::thread> th;
+    for (uint64_t d = 1; d < nctx; d++)
+        th.emplace_back([&, d] { encode_on_ctx(*ctx[d], E, J, d, nctx); });
+    encode_on_ctx(*ctx[0], E, J, 0, nctx);
+    for (auto &t : th)
+        t.join();
+    if (caller_dev >= 0)
+        (void)hipSetDevice(caller_dev);
+    if (J.error != REDUX_OK)
+        return J.error;
+    return J.bad_status;
 }
 
 // ================================================================================================
@@ -466,149 +610,199 @@ static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_l
 typedef int (*DecodeDevCall)(const redux_params *, const void *, const void *, uint64_t, uint32_t, void *, uint64_t, void *, void *,
                              void *, void *, uint64_t, void *, void *, const redux_block *, bool, uint64_t);
 
-static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
-                         uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes, int32_t *block_status,
-                         uint64_t *in_used, DecodeDevCall dev_call)
-{
-    Ctx *cp = nullptr;
-    int  rc = ctx_of_current_device(&cp);
-    if (rc != REDUX_OK)
-        return rc;
-    Ctx &c = *cp;
-    std::lock_guard<std::mutex> lock(c.mu);
-    if ((rc = ctx_init_locked(c)) != REDUX_OK)
-        return rc;
+struct DecCall {
+    const redux_params *p;
+    const uint8_t      *in;
+    const uint64_t     *in_offsets;
+    uint64_t            nblocks;
+    uint32_t            block_size;
+    uint8_t            *out;
+    uint32_t           *out_sizes;
+    int32_t            *block_status;
+    uint64_t           *in_used;
+    DecodeDevCall       dev_call;
+    uint64_t            cb, nchunks, wsb, max_in;
+};
 
-    const uint64_t cb      = chunk_blocks_for(nblocks, block_size, kDecChunkMax);
-    const uint64_t nchunks = (nblocks + cb - 1) / cb;
-    const uint64_t wsb     = redux_decode_workspace_bytes(p, cb, block_size);
-    uint64_t       max_in  = 0;
-    for (uint64_t k = 0; k < nchunks; k++) {
-        const uint64_t b0 = k * cb, b1 = (b0 + cb <= nblocks ? b0 + cb : nblocks);
-        if (in_offsets[b1] < in_offsets[b0])
-            return REDUX_INVALID_INPUT;
-        const uint64_t n = in_offsets[b1] - in_offsets[b0];
-        max_in = n > max_in ? n : max_in;
-    }
-    const int nslots = (int)(nchunks < (uint64_t)kSlots ? nchunks : (uint64_t)kSlots);
+static void decode_on_ctx(Ctx &c, const DecCall &D, Job &J, uint64_t first, uint64_t stride)
+{
+    if (hipSetDevice(c.device) != hipSuccess)
+        return J.fail(REDUX_IO_ERROR);
+    int rc = ctx_init_locked(c);
+    if (rc != REDUX_OK)
+        return J.fail(rc);
+    const uint64_t mine   = first < D.nchunks ? (D.nchunks - first + stride - 1) / stride : 0;
+    const int      nslots = (int)(mine < (uint64_t)kSlots ? mine : (uint64_t)kSlots);
     for (int i = 0; i < nslots; i++) {
         Slot &s = c.slot[i];
-        if ((rc = grow_dev(c, s.d_in, max_in + 32)) || (rc = grow_dev(c, s.d_ws, wsb + 256)) ||
-            (rc = grow_dev(c, s.d_out, cb * (uint64_t)block_size + 16)) || (rc = grow_dev(c, s.d_off, (cb + 1) * 8)) ||
-            (rc = grow_dev(c, s.d_sz, cb * 4)) || (rc = grow_dev(c, s.d_st, cb * 4)) || (rc = grow_dev(c, s.d_sum, 8)) ||
-            (rc = grow_dev(c, s.d_used, in_used ? cb * 8 : 8)) || (rc = grow_pinned(c, s.h_off, (cb + 1) * 8)) ||
-            (rc = grow_pinned(c, s.h_sz, cb * 4)) || (rc = grow_pinned(c, s.h_st, cb * 4)) || (rc = grow_pinned(c, s.h_sum, 8)) ||
-            (rc = grow_pinned(c, s.h_used, in_used ? cb * 8 : 8)))
-            return rc;
+        if ((rc = grow_dev(c, s.d_in, D.max_in + 32)) || (rc = grow_dev(c, s.d_ws, D.wsb + 256)) ||
+            (rc = grow_dev(c, s.d_out, D.cb * (uint64_t)D.block_size + 16)) || (rc = grow_dev(c, s.d_off, (D.cb + 1) * 8)) ||
+            (rc = grow_dev(c, s.d_sz, D.cb * 4)) || (rc = grow_dev(c, s.d_st, D.cb * 4)) || (rc = grow_dev(c, s.d_sum, 8)) ||
+            (rc = grow_dev(c, s.d_used, D.in_used ? D.cb * 8 : 8)) || (rc = grow_pinned(c, s.h_off, (D.cb + 1) * 8)) ||
+            (rc = grow_pinned(c, s.h_sz, D.cb * 4)) || (rc = grow_pinned(c, s.h_st, D.cb * 4)) || (rc = grow_pinned(c, s.h_sum, 8)) ||
+            (rc = grow_pinned(c, s.h_used, D.in_used ? D.cb * 8 : 8)))
+            return J.fail(rc);
     }
-
-    c.trace.assign(nchunks * 4, 0.0);
+    c.trace.assign(mine * 4, 0.0);
     c.t0 = now_s();
     Handover H;
-    int      first_bad = REDUX_OK;
     std::thread drain([&] {
         (void)hipSetDevice(c.device);
-        for (uint64_t k = 0; k < nchunks; k++) {
+        for (uint64_t j = 0; j < mine; j++) {
+            const uint64_t k = first + j * stride;
             {
                 std::unique_lock<std::mutex> l(H.m);
-                H.cv.wait(l, [&] { return H.issued > k || H.abort; });
+                H.cv.wait(l, [&] { return H.issued > j || H.abort; });
                 if (H.abort)
                     return;
             }
-            Slot          &s  = c.slot[k % kSlots];
-            const uint64_t b0 = k * cb, nb = (b0 + cb <= nblocks ? cb : nblocks - b0);
+            Slot          &s  = c.slot[j % kSlots];
+            const uint64_t b0 = k * D.cb, nb = (b0 + D.cb <= D.nblocks ? D.cb : D.nblocks - b0);
             int            err = REDUX_OK;
-            hipStream_t st = c.stream[k % kStreams];
+            hipStream_t st = c.stream[j % kStreams];
             if (hipEventSynchronize(s.done) != hipSuccess ||
                 hipMemcpyAsync(s.h_sz.p, s.d_sz.p, nb * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(s.h_sum.p, s.d_sum.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                (in_used && hipMemcpyAsync(s.h_used.p, s.d_used.p, nb * 8, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+                (D.in_used && hipMemcpyAsync(s.h_used.p, s.d_used.p, nb * 8, hipMemcpyDeviceToHost, st) != hipSuccess) ||
                 hipStreamSynchronize(st) != hipSuccess)
                 err = REDUX_IO_ERROR;
-            c.trace[k * 4 + 2] = now_s() - c.t0;
+            c.trace[j * 4 + 2] = now_s() - c.t0;
             if (!err) {
-                const int32_t *sum = (const int32_t *)s.h_sum.p;
-                if (first_bad == REDUX_OK && sum[0] != REDUX_OK)
-                    first_bad = sum[0];
-                err = drain_d2h(c, out + b0 * (uint64_t)block_size, s.d_out.p, nb * (uint64_t)block_size);
+                if (((const int32_t *)s.h_sum.p)[0] != REDUX_OK)
+                    J.note_bad(k, ((const int32_t *)s.h_sum.p)[0]);
+                err = drain_d2h(c, D.out + b0 * (uint64_t)D.block_size, s.d_out.p, nb * (uint64_t)D.block_size);
             }
             if (!err) {
-                memcpy(out_sizes + b0, s.h_sz.p, nb * 4);
-                if (block_status)
-                    memcpy(block_status + b0, s.h_st.p, nb * 4);
-                if (in_used)
-                    memcpy(in_used + b0, s.h_used.p, nb * 8);
+                memcpy(D.out_sizes + b0, s.h_sz.p, nb * 4);
+                if (D.block_status)
+                    memcpy(D.block_status + b0, s.h_st.p, nb * 4);
+                if (D.in_used)
+                    memcpy(D.in_used + b0, s.h_used.p, nb * 8);
             }
-            c.trace[k * 4 + 3] = now_s() - c.t0;
+            c.trace[j * 4 + 3] = now_s() - c.t0;
+            if (err)
+                J.fail(err);
             std::lock_guard<std::mutex> l(H.m);
-            if (err && H.error == REDUX_OK)
-                H.error = err;
-            H.drained = k + 1;
-            H.cv.notify_all();
-            if (err) {
+            H.drained = j + 1;
+            if (err)
                 H.abort = true;
+            H.cv.notify_all();
+            if (err)
                 return;
-            }
         }
     });
 
     {
         CopyPool pool(kCopyThreads - 1);
         uint64_t piece_no = 0;
-        for (uint64_t k = 0; k < nchunks && rc == REDUX_OK; k++) {
+        for (uint64_t j = 0; j < mine; j++) {
+            const uint64_t k = first + j * stride;
             {
                 std::unique_lock<std::mutex> l(H.m);
-                H.cv.wait(l, [&] { return H.abort || k < (uint64_t)kSlots || H.drained + kSlots > k; });
+                H.cv.wait(l, [&] { return H.abort || j < (uint64_t)kSlots || H.drained + kSlots > j; });
                 if (H.abort)
                     break;
             }
-            c.trace[k * 4 + 0] = now_s() - c.t0;
-            Slot          &s  = c.slot[k % kSlots];
-            hipStream_t    st = c.stream[k % kStreams];
-            const uint64_t b0 = k * cb, nb = (b0 + cb <= nblocks ? cb : nblocks - b0);
-            const uint64_t i0 = in_offsets[b0], len = in_offsets[b0 + nb] - i0;
+            {
+                std::lock_guard<std::mutex> l(J.m);
+                if (J.abort)
+                    break;
+            }
+            c.trace[j * 4 + 0] = now_s() - c.t0;
+            Slot          &s  = c.slot[j % kSlots];
+            hipStream_t    st = c.stream[j % kStreams];
+            const uint64_t b0 = k * D.cb, nb = (b0 + D.cb <= D.nblocks ? D.cb : D.nblocks - b0);
+            const uint64_t i0 = D.in_offsets[b0], len = D.in_offsets[b0 + nb] - i0;
             auto issue = [&]() -> int {
                 // the chunk's offsets, rebased to the chunk's first byte (the pinned mirror of the previous
                 // chunk in this slot has been consumed: that chunk is drained)
                 uint64_t *ho = (uint64_t *)s.h_off.p;
                 for (uint64_t i = 0; i <= nb; i++) {
-                    if (in_offsets[b0 + i] < i0 || (i && in_offsets[b0 + i] < in_offsets[b0 + i - 1]))
+                    if (D.in_offsets[b0 + i] < i0 || (i && D.in_offsets[b0 + i] < D.in_offsets[b0 + i - 1]))
                         return REDUX_INVALID_INPUT;
-                    ho[i] = in_offsets[b0 + i] - i0;
+                    ho[i] = D.in_offsets[b0 + i] - i0;
                 }
                 HOST_TRY(hipMemcpyAsync(s.d_off.p, ho, (nb + 1) * 8, hipMemcpyHostToDevice, st));
-                int r = stage_h2d(c, pool, piece_no, s.d_in.p, in + i0, len, st);
+                int r = stage_h2d(c, pool, piece_no, s.d_in.p, D.in + i0, len, st);
                 if (r != REDUX_OK)
                     return r;
                 HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
                 uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
-                r = dev_call(p, s.d_in.p, s.d_off.p, nb, block_size, s.d_out.p, nb * (uint64_t)block_size, s.d_sz.p, s.d_st.p,
-                             s.d_sum.p, ws, wsb, st, in_used ? s.d_used.p : nullptr, nullptr, false, 0);
+                r = D.dev_call(D.p, s.d_in.p, s.d_off.p, nb, D.block_size, s.d_out.p, nb * (uint64_t)D.block_size, s.d_sz.p, s.d_st.p,
+                               s.d_sum.p, ws, D.wsb, st, D.in_used ? s.d_used.p : nullptr, nullptr, false, 0);
                 if (r != REDUX_OK)
                     return r;
-                HOST_TRY(hipEventRecord(s.done, st)); // (small result arrays: fetched by the drain thread, see encode_blocks)
+                HOST_TRY(hipEventRecord(s.done, st)); // (small result arrays: fetched by the drain thread, see encode_on_ctx)
                 return REDUX_OK;
             };
             rc = issue();
-            c.trace[k * 4 + 1] = now_s() - c.t0;
+            c.trace[j * 4 + 1] = now_s() - c.t0;
+            if (rc != REDUX_OK)
+                J.fail(rc);
             std::lock_guard<std::mutex> l(H.m);
-            if (rc != REDUX_OK) {
+            if (rc != REDUX_OK)
                 H.abort = true;
-                if (H.error == REDUX_OK)
-                    H.error = rc;
-            } else
-                H.issued = k + 1;
+            else
+                H.issued = j + 1;
+            H.cv.notify_all();
+            if (rc != REDUX_OK)
+                break;
+        }
+        {
+            std::lock_guard<std::mutex> l(H.m);
+            if (H.issued < mine)
+                H.abort = true;
             H.cv.notify_all();
         }
     }
     drain.join();
     for (int i = 0; i < kStreams; i++)
         (void)hipStreamSynchronize(c.stream[i]);
+}
+
+static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint64_t nblocks,
+                         uint32_t block_size, uint8_t *out, uint64_t out_cap, uint32_t *out_sizes, int32_t *block_status,
+                         uint64_t *in_used, DecodeDevCall dev_call)
+{
     (void)out_cap;
-    if (H.error != REDUX_OK)
-        return H.error;
-    return first_bad;
+    std::vector<Ctx *> ctx;
+    int rc = contexts_for_call(ctx);
+    if (rc != REDUX_OK)
+        return rc;
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (Ctx *c : ctx)
+        locks.emplace_back(c->mu);
+    int caller_dev = -1;
+    (void)hipGetDevice(&caller_dev);
+
+    DecCall D;
+    D.p = p; D.in = in; D.in_offsets = in_offsets; D.nblocks = nblocks; D.block_size = block_size; D.out = out;
+    D.out_sizes = out_sizes; D.block_status = block_status; D.in_used = in_used; D.dev_call = dev_call;
+    D.cb      = chunk_blocks_for(nblocks, block_size, kDecChunkMax, ctx.size());
+    D.nchunks = (nblocks + D.cb - 1) / D.cb;
+    D.wsb     = redux_decode_workspace_bytes(p, D.cb, block_size);
+    D.max_in  = 0;
+    for (uint64_t k = 0; k < D.nchunks; k++) {
+        const uint64_t b0 = k * D.cb, b1 = (b0 + D.cb <= nblocks ? b0 + D.cb : nblocks);
+        if (in_offsets[b1] < in_offsets[b0])
+            return REDUX_INVALID_INPUT;
+        const uint64_t n = in_offsets[b1] - in_offsets[b0];
+        D.max_in = n > D.max_in ? n : D.max_in;
+    }
+    Job J;
+    const uint64_t nctx = ctx.size() < D.nchunks ? ctx.size() : D.nchunks;
+    std::vector<std::thread> th;
+    for (uint64_t d = 1; d < nctx; d++)
+        th.emplace_back([&, d] { decode_on_ctx(*ctx[d], D, J, d, nctx); });
+    decode_on_ctx(*ctx[0], D, J, 0, nctx);
+    for (auto &t : th)
+        t.join();
+    if (caller_dev >= 0)
+        (void)hipSetDevice(caller_dev);
+    if (J.error != REDUX_OK)
+        return J.error;
+    return J.bad_status;
 }
 
 // ================================================================================================
@@ -622,15 +816,31 @@ static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_
 // ================================================================================================
 constexpr uint64_t kVGroupBytes = 512ull << 20;
 
+struct DeviceScope { // makes `dev` HIP's current device for a scope and puts the caller's back
+    int prev = -1;
+    explicit DeviceScope(int dev)
+    {
+        (void)hipGetDevice(&prev);
+        if (dev != prev)
+            (void)hipSetDevice(dev);
+    }
+    ~DeviceScope()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
 static int encode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len, uint64_t ninputs,
                            uint32_t block_size, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
 {
-    Ctx *cp = nullptr;
-    int  rc = ctx_of_current_device(&cp);
+    std::vector<Ctx *> ctx;
+    int rc = contexts_for_call(ctx);
     if (rc != REDUX_OK)
         return rc;
-    Ctx &c = *cp;
+    Ctx &c = *ctx[0]; // (a fleet's first context: a batch is one launch)
     std::lock_guard<std::mutex> lock(c.mu);
+    DeviceScope scope(c.device);
     if ((rc = ctx_init_locked(c)) != REDUX_OK)
         return rc;
     Slot       &s  = c.slot[0];
@@ -698,12 +908,13 @@ static int decode_blocks_v(const redux_params *p, const uint8_t *in, const uint6
                            const uint64_t *out_len, uint64_t ninputs, uint32_t block_size, uint32_t *out_sizes, int32_t *block_status,
                            DecodeDevCall dev_call)
 {
-    Ctx *cp = nullptr;
-    int  rc = ctx_of_current_device(&cp);
+    std::vector<Ctx *> ctx;
+    int rc = contexts_for_call(ctx);
     if (rc != REDUX_OK)
         return rc;
-    Ctx &c = *cp;
+    Ctx &c = *ctx[0];
     std::lock_guard<std::mutex> lock(c.mu);
+    DeviceScope scope(c.device);
     if ((rc = ctx_init_locked(c)) != REDUX_OK)
         return rc;
     Slot       &s  = c.slot[0];

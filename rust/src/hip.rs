@@ -53,6 +53,7 @@ extern "C" {
     fn redux_decompress(p: *const ReduxParams, input: *const u8, in_len: u64, out: *mut u8,
                         out_cap: u64, bytes_in: *mut u64, bytes_out: *mut u64) -> c_int;
     fn redux_host_release() -> c_int;
+    fn redux_host_set_devices(device_ids: *const i32, n: u32) -> c_int;
 }
 
 /// Status codes of include/redux_hip.h -> `redux::Error` (src/lib.rs:57-64).
@@ -87,6 +88,13 @@ pub fn release() {
     unsafe {
         redux_host_release();
     }
+}
+
+/// Several GPUs behind `compress_blocks` / `decompress_blocks`: every later call deals its chunks round-robin over one
+/// context per entry of `device_ids` (each fed over its own PCIe link; the devices exchange nothing).  An empty slice
+/// goes back to the default, HIP's current device.
+pub fn set_devices(device_ids: &[i32]) -> Result<()> {
+    unsafe { status(redux_host_set_devices(if device_ids.is_empty() { ptr::null() } else { device_ids.as_ptr() }, device_ids.len() as u32)) }
 }
 
 /// One `redux::compress` per block of `block_size` bytes, all blocks coded in parallel on the GPU.

@@ -165,3 +165,29 @@ def test_block_table_v_is_host_logic_and_orders_whole_blocks_first():
     tab = api.block_table_v([0, 0, 0, 0, 0], lens, 4096)
     assert sorted(int(e["index"]) for e in tab if e["index"] != api.BLOCK_IDLE) == list(range(6))
     assert api.BLOCK_DTYPE.itemsize == 16
+
+
+def test_host_chunk_plan_deals_whole_waves_round_robin():
+    # redux_host_chunk_plan: pure host arithmetic (what redux_encode_blocks / redux_decode_blocks do with a fleet of contexts)
+    for nblocks, bs, nctx, dec in [(65536, 65536, 1, False), (65536, 65536, 8, False), (65536, 65536, 8, True), (1000, 4096, 2, False),
+                                   (1, 65536, 8, False), (16384, 65536, 3, True), (200000, 1024, 4, False)]:
+        cb, nc = api.host_chunk_plan(nblocks, bs, nctx, dec)
+        assert cb >= 1 and (cb % 64 == 0 or cb == nblocks)          # whole waves of 64 blocks (or the whole small call)
+        assert (nc - 1) * cb < nblocks <= nc * cb                    # the chunks cover the blocks exactly
+        limit = (256 if dec else 128) << 20
+        assert cb * bs <= limit + 64 * bs                            # a chunk's payload stays under the limit (rounded up to a wave)
+        if nblocks * bs >= nctx * 8 * (16 << 20):                    # big calls: every context gets chunks, about eight each or more
+            per_ctx = [len(range(d, nc, nctx)) for d in range(nctx)]
+            assert min(per_ctx) >= 1 and max(per_ctx) - min(per_ctx) <= 1
+    # the test hook shrinks chunks so that a small input exercises slot reuse
+    api.host_set_chunk_bytes(1 << 20, 1 << 20)
+    try:
+        cb, nc = api.host_chunk_plan(65536, 4096, 2, False)
+        assert cb * 4096 == 1 << 20 and nc == 256
+    finally:
+        api.host_set_chunk_bytes(0, 0)
+    cb0, nc0 = api.host_chunk_plan(65536, 4096, 2, False)
+    assert cb0 * 4096 >= 16 << 20
+    L = _lib.lib()
+    assert L.redux_host_chunk_plan(0, 4096, 1, 0, C.byref(C.c_uint64()), C.byref(C.c_uint64())) == _lib.INVALID_INPUT
+    assert L.redux_host_chunk_plan(10, 4096, 17, 0, C.byref(C.c_uint64()), C.byref(C.c_uint64())) == _lib.INVALID_INPUT

@@ -1096,3 +1096,103 @@ def test_batch_decode_reports_damage_per_block_and_stays_inside_each_input(rx):
                                              (8, 30, 32), check=False)
     assert int(dst[b]) == 4 and int(sizes[b]) == 300          # OutputTooSmall, 300 bytes written
     assert dec[0].tobytes() == datas[0] and dec[2].tobytes() == datas[2]
+
+
+# ---- host pipeline: slot reuse, abort paths, several contexts (redux_amd/csrc/redux_host.hpp) ----
+def _mixed_bytes(n, seed):
+    rng = np.random.default_rng(seed)
+    text = np.frombuffer(open(os.path.join(GOLDEN, "corpora", "large", "bible.txt"), "rb").read(), dtype=np.uint8)
+    parts = [text, rng.integers(0, 256, 3_000_001, dtype=np.uint8), (rng.integers(0, 256, 2_000_000, dtype=np.uint8) >> 5)]
+    return np.resize(np.concatenate(parts), n)
+
+
+def test_host_pipeline_slot_reuse_with_small_chunks(rx):
+    """Chunk limits shrunk by the test hook: ~100 MB becomes 24 chunks on 8 slots, so every slot, stream, pinned piece and
+    the slot's pinned offset mirror are reused three times.  Streams against the single-call result; decode back."""
+    from redux_amd import api
+    data = _mixed_bytes(100_000_037, 11)
+    bs = 65536
+    ref_out, ref_offs, _ = rx.compress_blocks(data, bs, (8, 30, 32))
+    api.host_set_chunk_bytes(2 << 20, 2 << 20)
+    try:
+        cb, nc = api.host_chunk_plan((len(data) + bs - 1) // bs, bs, 1)
+        assert nc >= 20  # (2 MiB rounds up to a whole wave of 64 blocks: 4 MiB chunks, every slot used three times)
+        out, offs, st = rx.compress_blocks(data, bs, (8, 30, 32))
+        assert (offs == ref_offs).all() and (out == ref_out).all() and not st.any()
+        dec, sizes, dst = rx.decompress_blocks(out, offs, bs, (8, 30, 32))
+        assert not dst.any() and (dec[: len(data)] == data).all() and int(sizes.sum()) == len(data)
+    finally:
+        api.host_set_chunk_bytes(0, 0)
+
+
+def test_host_pipeline_aborts_cleanly_mid_pipeline(rx):
+    """Errors that only show in a LATE chunk, with many chunks in flight: an output buffer that runs out, and offsets that
+    stop being monotonic.  The call must come back with the right status and the library must keep working."""
+    import ctypes as C
+    from redux_amd import _lib, api
+    L = _lib.lib()
+    data = _mixed_bytes(60_000_000, 12)
+    bs = 65536
+    out, offs, _ = rx.compress_blocks(data, bs, (8, 30, 32))
+    nb = len(offs) - 1
+    cp = _lib.Params(8, 30, 32)
+    api.host_set_chunk_bytes(2 << 20, 2 << 20)
+    try:
+        small = np.empty(int(offs[nb // 2]) + 5, dtype=np.uint8)          # room for half of the streams only
+        o2 = np.zeros(nb + 1, dtype=np.uint64)
+        s2 = np.zeros(nb, dtype=np.int32)
+        st = L.redux_encode_blocks(C.byref(cp), data.ctypes.data, len(data), bs, small.ctypes.data, small.size, o2.ctypes.data, s2.ctypes.data)
+        assert st == _lib.OUTPUT_TOO_SMALL
+        bad = offs.copy()
+        bad[nb - 3] = bad[nb - 5]                                         # offsets go backwards in the last chunk
+        dec = np.empty(nb * bs, dtype=np.uint8)
+        sz = np.zeros(nb, dtype=np.uint32)
+        st = L.redux_decode_blocks(C.byref(cp), out.ctypes.data, bad.ctypes.data, nb, bs, dec.ctypes.data, dec.size, sz.ctypes.data, s2.ctypes.data)
+        assert st == _lib.INVALID_INPUT
+        # and the pipeline is intact afterwards
+        out3, offs3, _ = rx.compress_blocks(data, bs, (8, 30, 32))
+        assert (offs3 == offs).all() and (out3 == out).all()
+    finally:
+        api.host_set_chunk_bytes(0, 0)
+
+
+def test_host_calls_on_two_contexts_of_one_device(rx):
+    """redux_host_set_devices([0, 0]): two contexts on the one GPU this box has, chunks dealt round-robin, each context with its
+    own issuing and drain threads; the dense output is assembled in chunk order across both.  Same bytes as one context."""
+    from redux_amd import api
+    data = _mixed_bytes(90_000_011, 13)
+    bs = 65536
+    ref_out, ref_offs, _ = rx.compress_blocks(data, bs, (8, 30, 32))
+    api.host_set_chunk_bytes(4 << 20, 4 << 20)
+    try:
+        api.host_set_devices([0, 0])
+        out, offs, st = rx.compress_blocks(data, bs, (8, 30, 32))
+        assert (offs == ref_offs).all() and (out == ref_out).all() and not st.any()
+        dec, sizes, dst = rx.decompress_blocks(out, offs, bs, (8, 30, 32))
+        assert not dst.any() and (dec[: len(data)] == data).all()
+        # three contexts, a call of fewer chunks than contexts, and the batch call (context 0 of the fleet)
+        api.host_set_devices([0, 0, 0])
+        small = data[: 3 * bs + 17]
+        o1, of1, _ = rx.compress_blocks(small, bs, (8, 30, 32))
+        assert o1.tobytes() == ref_out[: int(ref_offs[3])].tobytes() + ox.compress(small[3 * bs:].tobytes(), (8, 30, 32))[0]
+        o2, of2, _, first = rx.compress_blocks_v([small.tobytes(), b"abc"], bs, (8, 30, 32))
+        assert o2[: int(of2[4])].tobytes() == o1.tobytes()
+        with pytest.raises(rx.InvalidInput):
+            api.host_set_devices([0, 99])
+    finally:
+        api.host_set_devices([])
+        api.host_set_chunk_bytes(0, 0)
+    out4, offs4, _ = rx.compress_blocks(data[: 10 * bs], bs, (8, 30, 32))
+    assert (offs4 == ref_offs[:11]).all()
+
+
+def test_gen_kernels_hand_large_blocks_to_the_one_lane_kernels(rx):
+    """A block of 4-bit symbols just above the lock-step kernels' 4 MiB limit (such blocks -- up to 256 MiB -- used to
+    come back Unsupported once 64 slots no longer fitted a 32-bit lane offset): the one-lane kernel codes it."""
+    rng = np.random.default_rng(5)
+    data = (rng.integers(0, 256, (4 << 20) + 4096, dtype=np.uint8) & 0x3F).tobytes()
+    out, offs, st = rx.compress_blocks(data, len(data), (4, 22, 24))
+    want, _ = ox.compress(data, (4, 22, 24))
+    assert out.tobytes() == want
+    dec, sizes, dst = rx.decompress_blocks(out, offs, len(data), (4, 22, 24))
+    assert int(sizes[0]) == len(data) and dec.tobytes() == data
