@@ -7,10 +7,12 @@
 //     (2^symbol_bits + 1 + symbols coded, until the freq_max freeze: adaptive_tree.rs:84) is WAVE-UNIFORM and the two
 //     u64 divisions of codec.rs:59-60 are multiplications by a per-step reciprocal (scale_div<FIXUP = true>: a block
 //     of 4-bit symbols passes count 2^17);
-//   * the Fenwick tree as u32 increments d[i] = tree[i] - lowbit(i), i = 1 .. 2^symbol_bits - 1, in per-lane
-//     columns: row e of lane l at e * 256 + 4 l.  4-bit symbols: 16 rows = 4 KiB of LDS per wave.  12-bit symbols:
-//     4096 rows = 1 MiB per wave in the workspace (global atomics; the rows a wave touches in one step are 12
-//     independent requests per lane, issued back to back; the tree of a small grid stays in L2);
+//   * the Fenwick tree as increments d[i] = tree[i] - lowbit(i), i = 1 .. 2^symbol_bits - 1, in LDS, in per-lane
+//     columns.  4-bit symbols: u32, row e of lane l at e * 256 + 4 l: 16 rows = 4 KiB per wave of 64 blocks.  12-bit
+//     symbols: 4096 nodes per block, so the LDS, not the wave width, sets how many blocks a CU holds: u16 nodes (blocks of
+//     at most 65535 symbols = 98,302 bytes; longer ones run on the one-lane kernels), two lanes to a dword, SIXTEEN live
+//     lanes per wave: 128 KiB, one workgroup per CU.  (Round 2 kept 64 trees of 1 MiB per wave in the workspace and walked them with global
+//     fetch-adds: 6.6 GB/s on the full grid, the atomics going to HBM.)
 //   * get_frequency = one fetch-add per level (addend 1 where update(s+1) increments the node, 0 where the prefix
 //     sums only read it) + two masked sums (adaptive_tree.rs:63-92), closed-form renormalisation and bit output
 //     exactly as encode_symbol (redux_coder.hpp); the decoder's descent probes the same nodes (adaptive_tree.rs:115-136);
@@ -31,22 +33,42 @@
 
 namespace redux {
 
-template <int SB>
+// INLDS (always for 4-bit symbols): the trees of a wave's blocks in LDS.  !INLDS (12-bit symbols, large grids, decode):
+// 64 trees of u32 per wave in the workspace, 1 MiB, walked with global loads and fetch-adds -- slower per step, but
+// 64 blocks per wave and several waves per SIMD instead of 16 blocks per CU: on the full grid the decoder, whose
+// descent is twelve DEPENDENT probes, is faster this way (6.5 against 4.2 GB/s), the encoder, whose twelve fetch-adds
+// are independent, in LDS (8.6 against 6.6 GB/s); below ~16,384 blocks both are 3 x faster in LDS.
+template <int SB, bool INLDS = true>
 struct GenTree {
-    static constexpr bool     kLds   = SB <= 8;
-    static constexpr uint32_t kRows  = 1u << SB;
-    static constexpr uint32_t kMask  = kRows - 1u;
-    static constexpr uint64_t kBytes = (uint64_t)kRows * 256; // per wave of 64 blocks
+    static constexpr bool     kU16    = INLDS && SB > 8;    // u16 nodes, lanes l and l + 8 in one dword
+    static constexpr uint32_t kBlocks = kU16 ? 16u : 64u;   // live lanes (= blocks) per wave
+    static constexpr uint32_t kRows   = 1u << SB;
+    static constexpr uint32_t kMask   = kRows - 1u;
+    static constexpr uint32_t kPitch  = kU16 ? 8u : 64u;    // dwords per row
+    static constexpr uint32_t kDwords = kRows * kPitch;     // 4-bit: 4 KiB; 12-bit: 128 KiB of LDS, or 1 MiB of workspace per wave
+    static constexpr uint32_t kLdsDwords = INLDS ? kDwords : 64u;
+    // u16 nodes hold increments: a node of a block of n symbols receives at most n of them
+    static constexpr uint32_t kMaxSymbols = SB > 8 ? 65535u : 0xFFFFFFFFu;
 
-    uint32_t *base; // row e of this lane: base[e * 64]  (base already points at the lane's column)
+    uint32_t *base; // row e of this lane: base[e * kPitch]  (base already points at the lane's dword column)
+    uint32_t  sh;   // kU16: bit position of this lane's half
 
+    __device__ __forceinline__ void init(uint32_t *mem, uint32_t lane) // mem: this wave's LDS array / workspace tree
+    {
+        base = mem + (kU16 ? (lane & 7u) : lane);
+        sh   = kU16 ? ((lane >> 3) & 1u) * 16u : 0u;
+    }
     __device__ __forceinline__ uint32_t fetch_add(uint32_t e, uint32_t v) const
     {
-        if (kLds)
-            return __hip_atomic_fetch_add(base + e * 64u, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return __hip_atomic_fetch_add(base + e * 64u, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t w = INLDS ? __hip_atomic_fetch_add(base + e * kPitch, v << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                 : __hip_atomic_fetch_add(base + e * kPitch, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return kU16 ? (w >> sh) & 0xFFFFu : w;
     }
-    __device__ __forceinline__ uint32_t load(uint32_t e) const { return base[e * 64u]; }
+    __device__ __forceinline__ uint32_t load(uint32_t e) const
+    {
+        const uint32_t w = base[e * kPitch];
+        return kU16 ? (w >> sh) & 0xFFFFu : w;
+    }
 
     // get_frequency(s) for a data symbol (adaptive_tree.rs:105-113); nup = updates so far, upd = the model is not frozen
     __device__ __forceinline__ void get_frequency(uint32_t s, uint32_t nup, bool upd, uint32_t &lo, uint32_t &hi) const
@@ -83,6 +105,25 @@ __device__ __forceinline__ uint32_t gen_symbol(const uint8_t *src, uint32_t k)
     }
 }
 
+// gen_symbol in two halves, so that a loop can LOAD the bytes of symbol k one step before it DECODES them (the value
+// that crosses the iteration is the raw load, which nothing waits for until it is decoded)
+template <int SB>
+__device__ __forceinline__ uint32_t gen_symbol_load(const uint8_t *src, uint32_t k)
+{
+    if (SB == 4)
+        return src[k >> 1];
+    const uint32_t i = k + (k >> 1);
+    return (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8);
+}
+template <int SB>
+__device__ __forceinline__ uint32_t gen_symbol_decode(uint32_t raw, uint32_t k)
+{
+    if (SB == 4)
+        return (k & 1u) ? (raw & 15u) : (raw >> 4);
+    const uint32_t b0 = raw & 0xFFu, b1 = raw >> 8;
+    return (k & 1u) ? (((b0 & 15u) << 8) | b1) : ((b0 << 4) | (b1 >> 4));
+}
+
 struct GenEncArgs {
     const uint8_t *in;
     uint64_t       in_len;
@@ -92,7 +133,6 @@ struct GenEncArgs {
     uint32_t      *sizes;
     int32_t       *status;
     const double  *rc;       // rc[i] = 1 / (2^SB + 1 + i), bumped (k_fill_rc_from)
-    uint32_t      *trees;    // SB 12: kRows * 64 u32 per wave, zero at launch
     uint32_t       block_size;
     uint32_t       slot_cap;
     uint32_t       nfreeze;  // freq_max - (2^SB + 1): updates before the freeze
@@ -112,18 +152,16 @@ template <int SB>
 __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
 {
     typedef GenTree<SB> Tree;
-    __shared__ uint32_t lds[Tree::kLds ? Tree::kRows * 64 : 64];
+    __shared__ uint32_t lds[Tree::kDwords];
     const uint32_t lane = threadIdx.x;
-    const uint64_t blk0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t blk0 = (uint64_t)blockIdx.x * Tree::kBlocks;
     const uint64_t blk  = blk0 + lane;
-    const bool     live = blk < a.nblocks;
-    if (Tree::kLds) {
-        for (uint32_t i = lane; i < Tree::kRows * 64; i += 64)
-            lds[i] = 0;
-        __syncthreads();
-    }
+    const bool     live = lane < Tree::kBlocks && blk < a.nblocks;
+    for (uint32_t i = lane; i < Tree::kDwords / 4; i += 64)
+        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
     Tree T;
-    T.base = (Tree::kLds ? lds : a.trees + (uint64_t)blockIdx.x * Tree::kRows * 64) + lane;
+    T.init(lds, lane);
 
     uint32_t len = 0;
     if (live) {
@@ -133,7 +171,7 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
     const uint32_t nsym   = (uint32_t)(((uint64_t)len * 8) / SB); // whole symbols; trailing bits are dropped (codec.rs:108)
     const uint8_t *src    = a.in + (live ? blk : blk0) * (uint64_t)a.block_size;
     uint8_t       *wdst   = a.slots + blk0 * a.slot_bytes;
-    const uint32_t off0   = live ? lane * (uint32_t)a.slot_bytes : (uint32_t)(a.nblocks - blk0) * (uint32_t)a.slot_bytes;
+    const uint32_t off0   = live ? lane * (uint32_t)a.slot_bytes : 0u; // (dead lanes store nothing: everything below is predicated)
     const uint32_t limit  = off0 + a.slot_cap;
     const uint32_t maxsym = __builtin_amdgcn_readfirstlane(wave_max(live ? nsym : 0u));
     const uint32_t sh     = 32 - a.code_bits;
@@ -143,13 +181,29 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
 
     EncState S;
     enc_init(S, off0);
+    // The symbol and the reciprocal of step p + 1 are loaded during step p: one wave per CU has nothing else to hide a
+    // load behind.  The symbol's load is unconditional (index clamped into the block; a lane without symbols reads its
+    // block's first bytes, or the buffer's for an empty input... never past what a.in holds), so that it is not followed
+    // by the wait a branch join would put behind it.
+    const uint32_t last_sym = nsym ? nsym - 1u : 0u;
+    const bool     can_load = live && nsym != 0;
+    const uint8_t *psrc     = can_load ? src : reinterpret_cast<const uint8_t *>(a.rc); // (always mapped, at least 33 doubles)
+    uint32_t       raw_next = gen_symbol_load<SB>(psrc, 0), k_next = 0;
+    double         r_next   = rc[0];
     for (uint32_t p = 0; p <= maxsym; p++) {
         const uint32_t nup = p < nfreeze ? p : nfreeze; // wave-uniform
-        const double   r   = rc[nup];
+        const double   r   = r_next;
         const uint32_t c   = kCount0 + nup;
+        const uint32_t sym = gen_symbol_decode<SB>(raw_next, k_next);
+        {
+            const uint32_t q = p + 1 < last_sym ? p + 1 : last_sym;
+            k_next           = can_load ? q : 0u;
+            raw_next         = gen_symbol_load<SB>(psrc, k_next);
+            r_next           = rc[p + 1 < nfreeze ? p + 1 : nfreeze]; // (the table has 32 entries of slack)
+        }
         if (live && p < nsym) {
             uint32_t lo, hi;
-            T.get_frequency(gen_symbol<SB>(src, p), nup, p < nfreeze, lo, hi);
+            T.get_frequency(sym, nup, p < nfreeze, lo, hi);
             encode_symbol<true>(S, lo, hi, c, r, sh, false, wdst, limit);
         } else if (live && p == nsym) {
             // EOF symbol (codec.rs:108): cum(2^SB) = count - 1, cum(2^SB + 1) = count
@@ -169,28 +223,28 @@ struct GenDecArgs {
     uint32_t       *out_sizes;
     int32_t        *status;
     const double   *rc;
-    uint32_t       *trees;      // SB 12
+    uint32_t       *trees;      // !INLDS: kRows * 64 u32 per wave, zero at launch
     uint64_t       *in_used;    // optional
     uint32_t        block_size;
     uint32_t        nfreeze;
     uint32_t        code_bits;
 };
 
-template <int SB>
+template <int SB, bool INLDS = true>
 __global__ void __launch_bounds__(64) k_decode_gen(GenDecArgs a)
 {
-    typedef GenTree<SB> Tree;
-    __shared__ uint32_t lds[Tree::kLds ? Tree::kRows * 64 : 64];
+    typedef GenTree<SB, INLDS> Tree;
+    __shared__ uint32_t lds[Tree::kLdsDwords];
     const uint32_t lane = threadIdx.x;
-    const uint64_t blk  = (uint64_t)blockIdx.x * 64 + lane;
-    const bool     live = blk < a.nblocks;
-    if (Tree::kLds) {
-        for (uint32_t i = lane; i < Tree::kRows * 64; i += 64)
-            lds[i] = 0;
+    const uint64_t blk  = (uint64_t)blockIdx.x * Tree::kBlocks + lane;
+    const bool     live = lane < Tree::kBlocks && blk < a.nblocks;
+    if (INLDS) {
+        for (uint32_t i = lane; i < Tree::kLdsDwords / 4; i += 64)
+            reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
     Tree T;
-    T.base = (Tree::kLds ? lds : a.trees + (uint64_t)blockIdx.x * Tree::kRows * 64) + lane;
+    T.init(INLDS ? lds : a.trees + (uint64_t)blockIdx.x * Tree::kDwords, lane);
 
     const uint32_t cb = a.code_bits, sh = 32 - cb;
     uint64_t       size = 0;

@@ -136,9 +136,18 @@ static bool is_any(const redux_params *p) { return p->symbol_bits != 8 || p->cod
 // for 4 MiB of 4-bit symbols) and address 64 slots / 64 blocks with 32-bit lane offsets; a bigger block -- whole-stream
 // mode, redux_compress / redux_decompress of a large buffer or with a large output capacity -- is one lane's serial chain
 // anyway and runs on the one-lane kernels, which have neither limit.
+// The 12-bit decoder keeps its trees in LDS (16 blocks per CU) on small grids and in the workspace (64 per wave, many waves per
+// CU) on large ones: see GenTree.
+static bool gen12_decode_in_workspace(const redux_params *p, uint64_t nblocks) { return p->symbol_bits == 12 && nblocks >= 16384; }
+
+// 12-bit symbols: the tree lives in LDS as u16 increments (redux_gen.hpp): blocks of at most 65535 symbols.
 static bool is_gen(const redux_params *p, uint32_t block_size)
 {
-    return (p->symbol_bits == 4 || p->symbol_bits == 12) && p->code_bits <= 32 && block_size <= (1u << 22);
+    if (p->code_bits > 32)
+        return false;
+    if (p->symbol_bits == 4)
+        return block_size <= (1u << 22);
+    return p->symbol_bits == 12 && (uint64_t)block_size * 8 / 12 <= GenTree<12>::kMaxSymbols;
 }
 
 static uint64_t slot_cap_for(const redux_params *p, uint32_t block_size)
@@ -193,7 +202,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     if (static_model)
         g.rc_n = 0;
     g.gen = !static_model && is_gen(p, block_size) && 64ull * g.slot_bytes < (1ull << 32); // (64 blocks: implied by is_gen)
-    if (g.gen) { // reciprocal table over the symbol count; 12-bit symbols: 4096 u32 rows x 64 lanes per wave in the workspace
+    if (g.gen) { // reciprocal table over the symbol count (the trees are in LDS)
         const uint64_t k0      = (1ull << p->symbol_bits) + 1;
         const uint64_t nsym    = maxlen * 8 / p->symbol_bits;
         const uint64_t nfreeze = freq_max - k0;
@@ -202,7 +211,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
         g.rc_n    = (uint32_t)((nsym < nfreeze ? nsym : nfreeze) + 1 + 32);
         g.u16     = false;
         g.fixup   = true;
-        g.tree_bytes = p->symbol_bits == 12 ? GenTree<12>::kBytes / 64 : 0;
+        g.tree_bytes = 0;
     }
     if (g.any) { // no reciprocal table; one tree of 2^symbol_bits + 2 u32 per block
         g.rc_n       = 0;
@@ -324,7 +333,7 @@ const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, ui
     case EncKernel::SingleU16Fixup: return "k_encode<true, true> (u16 tree, one wave per 64 blocks, quotient fix-up)";
     case EncKernel::SingleU32: return "k_encode<false, true> (u32 tree)";
     case EncKernel::Gen4: return "k_encode_gen<4> (4-bit symbols, lock-step, u32 tree in LDS)";
-    case EncKernel::Gen12: return "k_encode_gen<12> (12-bit symbols, lock-step, u32 tree in the workspace)";
+    case EncKernel::Gen12: return "k_encode_gen<12> (12-bit symbols, lock-step, u16 tree in LDS, 16 blocks per wave)";
     case EncKernel::Any: return "k_encode_any (general parameters, one lane per block)";
     }
     return "";
@@ -343,7 +352,7 @@ const char *redux_decode_kernel_name(const redux_params *p, const void *d_out, u
     case DecKernel::GenericU16Fixup: return "k_decode<true, true> (u16 tree, quotient fix-up)";
     case DecKernel::GenericU32: return "k_decode<false, true> (u32 tree)";
     case DecKernel::Gen4: return "k_decode_gen<4> (4-bit symbols, lock-step, u32 tree in LDS)";
-    case DecKernel::Gen12: return "k_decode_gen<12> (12-bit symbols, lock-step, u32 tree in the workspace)";
+    case DecKernel::Gen12: return "k_decode_gen<12> (12-bit symbols, lock-step; u16 trees in LDS, 16 blocks per wave, or -- 16,384 blocks and more -- u32 trees in the workspace, 64 per wave)";
     case DecKernel::Any: return "k_decode_any (general parameters, one lane per block)";
     }
     return "";
@@ -418,19 +427,16 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
         ga.sizes      = (uint32_t *)(ws + g.off_sizes);
         ga.status     = (int32_t *)d_block_status;
         ga.rc         = (const double *)(ws + g.off_rc);
-        ga.trees      = (uint32_t *)(ws + g.off_trees);
         ga.block_size = block_size;
         ga.slot_cap   = g.slot_cap;
         ga.nfreeze    = g.nfreeze;
         ga.code_bits  = p->code_bits;
-        const uint32_t grid = (uint32_t)((g.nblocks + 63) / 64); // (64 slots / blocks within a 32-bit lane offset: geometry())
+        // (64 slots / blocks within a 32-bit lane offset: geometry())
         k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)(ws + g.off_rc), g.rc_n, (1u << p->symbol_bits) + 1u);
         if (p->symbol_bits == 4)
-            k_encode_gen<4><<<grid, 64, 0, s>>>(ga);
-        else {
-            HIP_TRY(hipMemsetAsync(ws + g.off_trees, 0, (uint64_t)grid * GenTree<12>::kBytes, s)); // every tree starts at all-ones frequencies
-            k_encode_gen<12><<<grid, 64, 0, s>>>(ga);
-        }
+            k_encode_gen<4><<<(uint32_t)((g.nblocks + 63) / 64), 64, 0, s>>>(ga);
+        else
+            k_encode_gen<12><<<(uint32_t)((g.nblocks + GenTree<12>::kBlocks - 1) / GenTree<12>::kBlocks), 64, 0, s>>>(ga);
         HIP_TRY(hipGetLastError());
         return REDUX_OK;
     }
@@ -683,8 +689,9 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
     if (check_params(p) != REDUX_OK || block_size == 0)
         return 0;
     const Geometry g = geometry(p, block_size, block_size);
-    if (g.gen)
-        return align_up((uint64_t)g.rc_n * 8, 256) + ((nblocks ? nblocks : 1) + 63) / 64 * 64 * g.tree_bytes;
+    if (g.gen) // (12-bit symbols on a large grid decode with their trees in the workspace: gen12_decode_in_workspace)
+        return align_up((uint64_t)g.rc_n * 8, 256) +
+               (gen12_decode_in_workspace(p, nblocks) ? (nblocks + 63) / 64 * (uint64_t)GenTree<12, false>::kDwords * 4 : 0);
     if (g.any)
         return (nblocks ? nblocks : 1) * g.tree_bytes;
     return align_up((uint64_t)g.rc_n * 8, 256);
@@ -727,14 +734,15 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         ga.block_size = block_size;
         ga.nfreeze    = g.nfreeze;
         ga.code_bits  = p->code_bits;
-        const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
         k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)d_workspace, g.rc_n, (1u << p->symbol_bits) + 1u);
         if (p->symbol_bits == 4)
-            k_decode_gen<4><<<grid, 64, 0, s>>>(ga);
-        else {
-            HIP_TRY(hipMemsetAsync(ga.trees, 0, (uint64_t)grid * GenTree<12>::kBytes, s));
-            k_decode_gen<12><<<grid, 64, 0, s>>>(ga);
-        }
+            k_decode_gen<4><<<(uint32_t)((nblocks + 63) / 64), 64, 0, s>>>(ga);
+        else if (gen12_decode_in_workspace(p, nblocks)) {
+            const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
+            HIP_TRY(hipMemsetAsync(ga.trees, 0, (uint64_t)grid * GenTree<12, false>::kDwords * 4, s)); // every tree starts at all-ones frequencies
+            k_decode_gen<12, false><<<grid, 64, 0, s>>>(ga);
+        } else
+            k_decode_gen<12><<<(uint32_t)((nblocks + GenTree<12>::kBlocks - 1) / GenTree<12>::kBlocks), 64, 0, s>>>(ga);
         if (d_summary)
             k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
         HIP_TRY(hipGetLastError());

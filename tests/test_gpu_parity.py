@@ -1196,3 +1196,23 @@ def test_gen_kernels_hand_large_blocks_to_the_one_lane_kernels(rx):
     assert out.tobytes() == want
     dec, sizes, dst = rx.decompress_blocks(out, offs, len(data), (4, 22, 24))
     assert int(sizes[0]) == len(data) and dec.tobytes() == data
+
+
+def test_12_bit_decoder_on_a_large_grid_uses_workspace_trees(rx):
+    """16,384 blocks and more: k_decode_gen<12, false> (u32 trees in the workspace, 64 blocks per wave) instead of the LDS form.
+    Small blocks keep it quick: streams against the oracle on a sample, everything decoded back."""
+    rng = np.random.default_rng(21)
+    bs, nb = 96, 16400 + 37
+    data = (rng.integers(0, 256, bs * nb - 5, dtype=np.uint8) & rng.integers(1, 256, bs * nb - 5, dtype=np.uint8))
+    P = (12, 20, 32)
+    out, offs, st = rx.compress_blocks(data, bs, P)
+    assert not st.any()
+    for b in (0, 1, 8191, 16383, 16384, nb - 1):
+        want, _ = ox.compress(data[b * bs:(b + 1) * bs].tobytes(), P)
+        assert out[int(offs[b]): int(offs[b + 1])].tobytes() == want, b
+    dec, sizes, dst = rx.decompress_blocks(out, offs, bs, P)
+    assert not dst.any()
+    keep = bs * 8 // 12 * 12 // 8
+    assert (sizes[:-1] == keep).all()
+    got = dec.reshape(nb, bs)[:, :keep]
+    assert (got[:-1] == data[: (nb - 1) * bs].reshape(nb - 1, bs)[:, :keep]).all()
