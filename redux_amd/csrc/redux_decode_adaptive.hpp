@@ -191,6 +191,7 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
     const gptr      gin      = has ? (gptr)(sp_abs & ~(uintptr_t)3) : (gptr)(uintptr_t)a.in_offsets;
     const uint32_t  rpo_last = has ? (uint32_t)(((((sp_abs + size + 3) & ~(uintptr_t)3) - (sp_abs & ~(uintptr_t)3)) >> 2) - 1) : 0u;
     const uint32_t  skip     = has ? (uint32_t)(sp_abs & 3) * 8 : 0u;
+    const gptr      gsafe    = (gptr)(uintptr_t)a.in_offsets;
     const uint32_t  L4       = lane * 4u;
     auto rd = [&](uint32_t o) { return gin[o < rpo_last ? o : rpo_last]; };
     auto ring_write = [&](uint32_t chunk, const ad_u32x4 &x) {
@@ -222,11 +223,15 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
         const uint32_t c    = room ? wr : wr - 1u;
         const bool     tail = 4u * c + 3u > rpo_last;
         pend_chunk          = c;
-        if (!tail)
-            ldq = *reinterpret_cast<gptr4>(gin + 4u * c);
-        if (__builtin_amdgcn_ballot_w64(tail) != 0) { // the last chunk of a stream (or a lane without one): clamped dword loads
-            if (tail)
-                ldq = ad_u32x4{rd(4u * c), rd(4u * c + 1u), rd(4u * c + 2u), rd(4u * c + 3u)};
+        // (a chunk that crosses the end of its stream is loaded dword by dword with clamped indices, in a rarely entered
+        // block; the 16-byte load of such a lane reads the offsets table instead: always mapped, 16 bytes or more)
+        ldq = *reinterpret_cast<gptr4>(tail ? gsafe : gin + 4u * c);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tail) != 0, 0)) {
+            const ad_u32x4 t = ad_u32x4{rd(4u * c), rd(4u * c + 1u), rd(4u * c + 2u), rd(4u * c + 3u)};
+            ldq.x = tail ? t.x : ldq.x;
+            ldq.y = tail ? t.y : ldq.y;
+            ldq.z = tail ? t.z : ldq.z;
+            ldq.w = tail ? t.w : ldq.w;
         }
         wr += room ? 1u : 0u;
     };
@@ -304,6 +309,7 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
         uint32_t kp0 = 0x0130030Fu, kp1 = 0x00401004u; // bytes: n128, n64, n192, n32 | n96, n160, n224
         uint32_t k10001 = 0x10001u, k10000 = 0x10000u, k01010101 = 0x01010101u;
         asm volatile("" : "+v"(kp0), "+v"(kp1), "+v"(k10001), "+v"(k10000), "+v"(k01010101));
+        uint32_t left = stream_bits - S.consumed; // stream bits not pulled yet: its sign is read_bits' Err(Eof) (bitio/mod.rs:107)
         uint32_t r1 = ~(S.ihigh + S.low); // high - low of the interval, left-aligned: carried instead of ~high (see the commit)
         // range = high - low + 1 and its reciprocal are formed at the END of a step, as soon as the new interval is known:
         // the division chain of the next step's code value (codec.rs:131) starts under the rest of the commit
@@ -453,8 +459,8 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                     const uint32_t t2    = (low2 & ih2) << 1;
                     const uint32_t j     = (uint32_t)__builtin_clz(~t2);
                     const uint32_t n     = k + j; // bits pulled by get_bit (codec.rs:157)
-                    const uint32_t cons0 = S.consumed, cons2 = cons0 + n;
-                    uint32_t e     = (eofq | (stream_bits - cons2)) & livemask;
+                    const uint32_t left0 = left, left2 = left0 - n;
+                    uint32_t e     = (eofq | left2) & livemask;
                     // ---- E: commit, every lane.  The half of the octet cell that holds the quad of s: fields
                     // (+1 | +5, +2 | +6, +3 | +7, +4 | spare) get (bits 1, 0 clear; bit 1 clear; bit 1 set, bit 0 clear;
                     // bit 2 clear); issued at the top of the next step
@@ -473,7 +479,7 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                     const uint32_t Ls = low2 << j;
                     r1                = ~(Ls + (ih2 << j));
                     S.low             = Ls & 0x7FFFFFFFu;
-                    S.consumed        = cons2;
+                    left              = left2;
                     // [value | next 32 bits] << k, keep the top bit, << j, put it back (codec.rs:143-157).  A narrow code
                     // whose interval collapsed (k == code_bits) takes that top bit from the new bits: both shifts 64-bit.
                     const uint32_t nxt  = (uint32_t)(S.bbits >> 32);
@@ -491,7 +497,7 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                         const bool fin        = (int32_t)e < 0;
                         const bool eof_symbol = (int32_t)eofq < 0; // decided first: decompress_symbol returns before renormalising
                         S.st     = fin && !eof_symbol ? REDUX_EOF : S.st;
-                        fin_cons = fin ? (eof_symbol ? cons0 : cons2) : fin_cons;
+                        fin_cons = fin ? stream_bits - (eof_symbol ? left0 : left2) : fin_cons;
                         S.n_out  = fin ? p + 4 * G + K : S.n_out;
                         S.dflag  = fin ? 0x80000000u : S.dflag;
                         livemask = fin ? 0x7FFFFFFFu : livemask;
@@ -533,7 +539,8 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
             stored = p;
             staged = p;
         }
-        S.ihigh = (~r1 - S.low) & 0x7FFFFFFFu; // (the predicated loop keeps ~high)
+        S.ihigh = (~r1 - S.low) & 0x7FFFFFFFu; // (the predicated loop keeps ~high ...
+        S.consumed = stream_bits - left;        //  ... and counts the bits pulled)
     }
     if ((int32_t)S.dflag < 0) // finished in the loop above (or never live): what the garbage steps since then did not touch
         S.consumed = fin_cons;

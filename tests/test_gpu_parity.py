@@ -1187,15 +1187,26 @@ def test_host_calls_on_two_contexts_of_one_device(rx):
 
 
 def test_gen_kernels_hand_large_blocks_to_the_one_lane_kernels(rx):
-    """A block of 4-bit symbols just above the lock-step kernels' 4 MiB limit (such blocks -- up to 256 MiB -- used to
-    come back Unsupported once 64 slots no longer fitted a 32-bit lane offset): the one-lane kernel codes it."""
+    """Blocks beyond what the lock-step kernels for 4- and 12-bit symbols take (4-bit blocks of 12 - 256 MiB used to come
+    back Unsupported once 64 slots no longer fitted a 32-bit lane offset).  The limits are now part of the kernel choice -- 4 MiB
+    for 4-bit symbols, 65,535 symbols = 98,302 bytes for 12-bit ones (u16 tree nodes in LDS) -- and the one-lane kernels code what
+    is above them.  Checked here just above the 12-bit limit (the 4-bit one takes a minute on one lane)."""
+    from redux_amd import _lib
+    import ctypes as C
     rng = np.random.default_rng(5)
-    data = (rng.integers(0, 256, (4 << 20) + 4096, dtype=np.uint8) & 0x3F).tobytes()
-    out, offs, st = rx.compress_blocks(data, len(data), (4, 22, 24))
-    want, _ = ox.compress(data, (4, 22, 24))
+    data = (rng.integers(0, 256, 98_304 + 2000, dtype=np.uint8) & 0x3F).tobytes()
+    cp = _lib.Params(12, 20, 32)
+    assert b"k_encode_any" in _lib.lib().redux_encode_kernel_name(C.byref(cp), None, len(data), len(data))
+    assert b"k_encode_gen" in _lib.lib().redux_encode_kernel_name(C.byref(cp), None, 98_302, 98_302)
+    cp4 = _lib.Params(4, 22, 24)
+    assert b"k_encode_any" in _lib.lib().redux_encode_kernel_name(C.byref(cp4), None, (4 << 20) + 1, (4 << 20) + 1)
+    assert b"k_encode_gen" in _lib.lib().redux_encode_kernel_name(C.byref(cp4), None, 4 << 20, 4 << 20)
+    out, offs, st = rx.compress_blocks(data, len(data), (12, 20, 32))
+    want, _ = ox.compress(data, (12, 20, 32))
     assert out.tobytes() == want
-    dec, sizes, dst = rx.decompress_blocks(out, offs, len(data), (4, 22, 24))
-    assert int(sizes[0]) == len(data) and dec.tobytes() == data
+    dec, sizes, dst = rx.decompress_blocks(out, offs, len(data), (12, 20, 32))
+    keep = len(data) * 8 // 12 * 12 // 8
+    assert int(sizes[0]) == keep and dec[:keep].tobytes() == data[:keep]
 
 
 def test_12_bit_decoder_on_a_large_grid_uses_workspace_trees(rx):
