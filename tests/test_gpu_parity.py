@@ -1207,6 +1207,13 @@ def test_gen_kernels_hand_large_blocks_to_the_one_lane_kernels(rx):
     dec, sizes, dst = rx.decompress_blocks(out, offs, len(data), (12, 20, 32))
     keep = len(data) * 8 // 12 * 12 // 8
     assert int(sizes[0]) == keep and dec[:keep].tobytes() == data[:keep]
+    # the case ADVICE r2 named: one block of 4-bit symbols past the lock-step limit (about 50 s on one lane)
+    data = (rng.integers(0, 256, (4 << 20) + 4096, dtype=np.uint8) & 0x3F).tobytes()
+    out, offs, st = rx.compress_blocks(data, len(data), (4, 22, 24))
+    want, _ = ox.compress(data, (4, 22, 24))
+    assert out.tobytes() == want
+    dec, sizes, dst = rx.decompress_blocks(out, offs, len(data), (4, 22, 24))
+    assert int(sizes[0]) == len(data) and dec.tobytes() == data
 
 
 def test_12_bit_decoder_on_a_large_grid_uses_workspace_trees(rx):
