@@ -516,6 +516,7 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     const gptr      gin    = has ? (gptr)(sp_abs & ~(uintptr_t)3) : (gptr)(uintptr_t)a.in_offsets;
     const uint32_t  rpo_last = has ? (uint32_t)(((((sp_abs + size + 3) & ~(uintptr_t)3) - (sp_abs & ~(uintptr_t)3)) >> 2) - 1) : 0u;
     const uint32_t  skip   = has ? (uint32_t)(sp_abs & 3) * 8 : 0u;
+    const gptr      gsafe  = (gptr)(uintptr_t)a.in_offsets;
     auto rd = [&](uint32_t o) { return gin[o < rpo_last ? o : rpo_last]; };
     constexpr uint32_t RB = kModelBytes;
     auto ring_write = [&](uint32_t chunk, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
@@ -525,7 +526,8 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     auto ring_read = [&](uint32_t d) {
         return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds) + RB + ((d & 31u) << 8) + L);
     };
-    uint32_t rpo = 2, wr = 0;
+    uint32_t rpo = 2, wr = 0, pend_chunk = 0;
+    u32x4    ldq = {0, 0, 0, 0};
     DecLane  S;
     {
         uint32_t d0 = 0, d1 = 0;
@@ -536,14 +538,13 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
                 d1 = (has && rpo_last >= 1) ? __builtin_bswap32(x1) : 0u;
             }
             ring_write(wr, x0, x1, x2, x3);
+            ldq        = u32x4{x0, x1, x2, x3};
+            pend_chunk = wr; // (the first group "retires" chunk 5 once more)
         }
         S.bbits = (((uint64_t)d0 << 32) | d1) << skip;
         S.bcnt  = 64 - skip;
     }
     uint32_t fetched = ring_read(rpo);
-    bool     pend = false; // a chunk is in flight: requested by the previous group, not yet in the ring
-    uint32_t pend_chunk = 0;
-    u32x4    ldq = {0, 0, 0, 0};
     S.W = (uint32_t)((S.bbits >> 1) >> (63 - cb)) << sh; // codec.rs:124-127
     S.bbits <<= cb;
     S.bcnt -= cb;
@@ -583,9 +584,7 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     //   RETIRE  wait for the chunk requested a group ago and move it into the ring;
     //   STORE   the four symbols the previous group produced;
     //   REQUEST the next chunk.
-#define REDUX_DEC_RETIRE                                                                                               \
-    if (pend)                                                                                                          \
-        ring_write(pend_chunk, ldq.x, ldq.y, ldq.z, ldq.w);
+#define REDUX_DEC_RETIRE ring_write(pend_chunk, ldq.x, ldq.y, ldq.z, ldq.w);
     // Output: a finished group's dword is staged; 16-byte aligned blocks get one 16-byte store per
     // four groups (p is wave-uniform, so that is a scalar branch).  A 4-byte store every four steps
     // per lane is what the L2's background cleaning of resident dirty lines turns into ten times
@@ -609,19 +608,21 @@ __device__ __forceinline__ void decode_lock_body(const DecArgs &a, uint32_t *lds
     }
 #define REDUX_DEC_REQUEST                                                                                              \
     {                                                                                                                  \
-        const bool room = (int32_t)(4u * wr - rpo) <= 28;                                                              \
-        const bool tail = 4u * wr + 3u > rpo_last;                                                                     \
-        pend       = room;                                                                                             \
-        pend_chunk = wr;                                                                                               \
-        if (room && !tail)                                                                                             \
-            ldq = *reinterpret_cast<gptr4>(gin + 4u * wr);                                                             \
-        if (__builtin_amdgcn_ballot_w64(room && tail) != 0) {                                                          \
-            if (room && tail) {                                                                                        \
-                ldq.x = rd(4u * wr);                                                                                   \
-                ldq.y = rd(4u * wr + 1u);                                                                              \
-                ldq.z = rd(4u * wr + 2u);                                                                              \
-                ldq.w = rd(4u * wr + 3u);                                                                              \
-            }                                                                                                          \
+        /* chunk wr when its ring slot is free, otherwise chunk wr-1 once more (it lands on its own copy): the 16-byte \
+           load is unconditional, so no join of an exec-masked region makes the compiler wait for a load it has just   \
+           issued.  A chunk that crosses the end of its stream is read dword by dword with clamped indices in a rarely \
+           entered block; the 16-byte load of such a lane reads the offsets table instead (always mapped). */          \
+        const bool     room = (int32_t)(4u * wr - rpo) <= 28;                                                          \
+        const uint32_t c_   = room ? wr : wr - 1u;                                                                     \
+        const bool     tail = 4u * c_ + 3u > rpo_last;                                                                 \
+        pend_chunk          = c_;                                                                                      \
+        ldq = *reinterpret_cast<gptr4>(tail ? gsafe : gin + 4u * c_);                                                  \
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tail) != 0, 0)) {                                             \
+            const uint32_t t0 = rd(4u * c_), t1 = rd(4u * c_ + 1u), t2 = rd(4u * c_ + 2u), t3 = rd(4u * c_ + 3u);      \
+            ldq.x = tail ? t0 : ldq.x;                                                                                 \
+            ldq.y = tail ? t1 : ldq.y;                                                                                 \
+            ldq.z = tail ? t2 : ldq.z;                                                                                 \
+            ldq.w = tail ? t3 : ldq.w;                                                                                 \
         }                                                                                                              \
         wr += room ? 1u : 0u;                                                                                          \
     }
