@@ -1,0 +1,413 @@
+// redux_hip -- small grids: the model of a block computed by 64 lanes, the interval chain by one.
+//
+//   k_coop_model   one WAVE per block: lane j runs AdaptiveTreeModel over the j-th 64th of the block, starting from
+//                  the counts of everything before it, and leaves every symbol's (low, high) in the workspace
+//   k_coop_chain   one LANE per block (64 blocks per wave): compress_symbol's interval chain + bit output over those
+//                  pairs -- the coder wave of k_encode_pair with the LDS ring replaced by a prefetched global stream
+//
+// Why: with 64 blocks per wave a launch of n blocks keeps n / 64 SIMDs busy; below ~4096 blocks most of the chip idles
+// while every block still pays the full serial price, 65,536 symbols x (model wave's issue time) = 10 ms.  But what
+// get_frequency_range(s) returns for symbol i (adaptive_tree.rs:63-92) depends only on the COUNTS of symbols 0 .. i-1,
+// not on the coder's state: counts are prefix statistics of the input and parallelise exactly.  Lane j histograms its
+// segment, an exclusive scan across the lanes gives every segment its starting counts, each lane builds the Fenwick form
+// of those and then runs the ordinary query + update over its 1/64th.  Only codec.rs:55-60's chain (low, high depend on
+// the previous symbol's) stays serial, and a wave that does nothing else retires a symbol in ~50 instructions.
+//
+// The pairs are stored symbol-major per group of 64 blocks, pairs[(group * (block_size + slack) + i) * 64 + lane], so the chain
+// wave reads 512 contiguous bytes per symbol.  Chosen by geometry() (redux_hip.hip) for launches of at most
+// kCoopMaxBlocks blocks whose model neither freezes inside a block nor needs u32 nodes; results are the same bytes
+// as every other kernel's (tests/test_gpu_parity.py: the corpus and batch tests run on it).
+//
+// Included by redux_hip.hip (one translation unit).
+#pragma once
+
+#include "redux_coder.hpp"
+#include "redux_encode.hpp"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace redux {
+
+constexpr uint64_t kCoopMaxBlocks = 1024; // (the pairs take 8 bytes per input byte of workspace: 512 MiB at 1024 x 64 KiB)
+constexpr uint32_t kCoopMinBlock  = 1024; // shorter blocks: the per-block set-up (scan, tree build) outweighs the model
+constexpr uint32_t kCoopSlack     = 64;   // symbols of slack behind a group's pairs (the chain wave prefetches unclamped)
+
+// inclusive sum over the wave's lanes 0 .. lane
+__device__ __forceinline__ uint32_t coop_wave_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t w = __shfl_up(v, o);
+        v += lane >= (uint32_t)o ? w : 0u;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
+{
+    __shared__ uint32_t lds[Tree<true>::kDwords];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t ent  = blockIdx.x; // the slot: lane ent & 63 of chain wave ent >> 6
+    const uint8_t *src;
+    uint32_t       len;
+    if (a.table) {
+        const redux_block e = a.table[ent];
+        if (e.index == kIdleEntry)
+            return;
+        src = a.in + e.offset;
+        len = e.length;
+    } else {
+        if (ent >= a.nblocks)
+            return;
+        const uint64_t rem = a.in_len - ent * a.block_size;
+        src = a.in + ent * a.block_size;
+        len = rem < a.block_size ? (uint32_t)rem : a.block_size;
+    }
+    if (len == 0)
+        return;
+    for (uint32_t i = lane; i < Tree<true>::kDwords / 4; i += 64)
+        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    Tree<true> T;
+    T.init(lds, lane);
+    __syncthreads();
+
+    // this lane's symbols [b0, b1), read as the aligned 16-byte pieces of memory that contain them (the bytes of a piece
+    // outside the block are in the same page as bytes inside it)
+    const uint32_t  seg = (len + 63) / 64;
+    const uint32_t  b0 = lane * seg < len ? lane * seg : len, b1 = b0 + seg < len ? b0 + seg : len;
+    const uintptr_t A0 = (uintptr_t)src + b0, A1 = (uintptr_t)src + b1, C0 = A0 & ~(uintptr_t)15;
+    const uint32_t  npieces = b1 > b0 ? (uint32_t)((A1 - C0 + 15) >> 4) : 0u;
+    const uint32_t  maxpieces = __builtin_amdgcn_readfirstlane(wave_max(npieces));
+    auto piece = [&](uint32_t k) { return *reinterpret_cast<const uint4 *>(C0 + 16 * (uintptr_t)(k < npieces ? k : 0)); };
+
+    // ---- 1. counts of this segment: row s + 1 of the lane's column (row 0 takes symbol 255, whose count no prefix needs)
+    {
+        uint4 nx = npieces ? piece(0) : make_uint4(0, 0, 0, 0);
+        for (uint32_t k = 0; k < maxpieces; k++) {
+            const uint4 cur = nx;
+            if (k + 1 < npieces)
+                nx = piece(k + 1);
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uintptr_t ad = C0 + 16 * (uintptr_t)k + i;
+                const uint32_t  s  = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                if (k < npieces && ad >= A0 && ad < A1)
+                    T.add((((s + 1u) & 255u) << Tree<true>::kShift) | T.L, T.inc);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. row r: counts of symbol r - 1 in the segments BEFORE this lane's (exclusive scan over the lanes)
+    for (uint32_t r = 1; r < 256; r++) {
+        const uint32_t v    = T.node((r << Tree<true>::kShift) | T.L);
+        const uint32_t incl = coop_wave_scan(v, lane);
+        *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lds) + ((r << Tree<true>::kShift) | T.L) + 2 * (lane >> 5)) = (uint16_t)(incl - v);
+    }
+    __syncthreads();
+    // ---- 3. the Fenwick form in place (node i also covers node i - lowbit(i) + ... : adaptive_tree.rs:43-59): d[i] is
+    //         the number of increments node i has received after the symbols before this segment
+    for (uint32_t i = 1; i < 256; i++) {
+        const uint32_t j = i + (i & (0u - i));
+        if (j < 256) {
+            const uint32_t v = T.node((i << Tree<true>::kShift) | T.L);
+            T.add((j << Tree<true>::kShift) | T.L, v << T.hsh);
+        }
+    }
+    // ---- 4. query + update over the segment (adaptive_tree.rs:63-92), pairs out
+    uint2 *pg = pairs + ((ent >> 6) * ((uint64_t)a.block_size + kCoopSlack)) * 64 + (ent & 63);
+    {
+        uint4 nx = npieces ? piece(0) : make_uint4(0, 0, 0, 0);
+        for (uint32_t k = 0; k < maxpieces; k++) {
+            const uint4 cur = nx;
+            if (k + 1 < npieces)
+                nx = piece(k + 1);
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll 4
+            for (int i = 0; i < 16; i++) {
+                const uintptr_t ad = C0 + 16 * (uintptr_t)k + i;
+                const uint32_t  s  = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                if (k < npieces && ad >= A0 && ad < A1) {
+                    const uint32_t q = (uint32_t)(ad - (uintptr_t)src); // symbols (= updates) before this one
+                    uint32_t       lo, hi;
+                    // (the update of a block's last symbol is unobservable and skipped: u16 nodes, Tree)
+                    T.template get_frequency<true>(s, q, q + 1 != len, lo, hi);
+                    pg[(uint64_t)q * 64] = make_uint2(lo, hi);
+                }
+            }
+        }
+    }
+}
+
+// ======================================================================================
+// The chain.  compress_symbol (codec.rs:55-89) has two halves that only talk one way: the interval (low, high -> the k
+// bits low and high now share, the j E3 steps, the next low and high) never looks at the bit writer, and the bit writer
+// (put_bit with its pending count, codec.rs:39-46, and bitio/mod.rs:148-181) needs only (those k bits, k, j).  So the
+// workgroup is two waves on two SIMDs with an LDS ring between them:
+//   wave 0, CHAIN: pairs from the workspace (requested two chunks ahead) -> narrowing + closed-form renormalisation
+//                  (redux_coder.hpp, encode_symbol) -> one message (top k bits, k | j << 8) per symbol;
+//   wave 1, EMIT : messages -> pending-bit bookkeeping, 64-bit accumulator, 4-byte stores into the row-major group area
+//                  (what k_encode_pair's coder wave does after its narrowing), the EOF tail and the sizes.
+// A lone wave issues one instruction per 4-5 cycles whatever it depends on (profiles/r01_ubench/lone_wave_gfx950.txt),
+// so what counts is the instruction count of the longer half: ~25 and ~30 per symbol against the ~50 of both together.
+// The ring holds two periods of kPeriod symbols (ds_write_b128 / ds_read_b128 of two symbols, as k_encode_pair's ring);
+// one s_barrier per period hands a half over.  Both waves derive the same schedule from wave-uniform values: chunks of
+// 16 symbols below main_end are lock-step with no lane predicate; from there to the longest block's EOF every symbol is
+// predicated per lane (a lane past its EOF sends the empty message k = j = 0, which the bit writer ignores).
+// ======================================================================================
+constexpr uint32_t kPeriod    = 32;                        // symbols per hand-off
+constexpr uint32_t kCoopRing  = 2 * kPeriod * 64 * 8;      // two periods of uint2[kPeriod][64]
+
+struct ChainState {
+    uint32_t low, ih, r1; // low and ~high left-aligned (ih with a stray bit 31, see encode_symbol_spec), r1 = high - low
+};
+
+// the narrowing half of encode_symbol_spec: all lanes live, data symbols only
+template <bool CB32>
+__device__ __forceinline__ uint2 chain_step(ChainState &X, uint32_t lo, uint32_t hi, uint32_t c, double rc, uint32_t sh_)
+{
+    const uint32_t sh = CB32 ? 0u : sh_;
+    const uint32_t R1 = X.r1 >> sh;
+    const double   Y  = __builtin_fma((double)R1, rc, rc);
+    const uint32_t nlow   = X.low + (scale_div<false>(R1, Y, lo, c) << sh);
+    const uint32_t nihigh = 0u - (X.low + (scale_div<false, true>(R1, Y, hi, c) << sh));
+    const uint32_t x      = ~(nlow ^ nihigh);
+    const uint32_t k      = CB32 ? (uint32_t)__builtin_clz(x) : (x ? (uint32_t)__builtin_clz(x) : 32u);
+    const uint64_t sl     = (uint64_t)nlow << k;
+    const uint32_t ih2    = CB32 ? nihigh << k : (uint32_t)((uint64_t)nihigh << k);
+    const uint32_t low2   = (uint32_t)sl;
+    const uint32_t nt     = ((~(low2 & ih2)) << 1) | 1u;
+    const uint32_t j      = (uint32_t)__builtin_clz(nt);
+    const uint32_t L      = low2 << j;
+    X.ih  = ih2 << j;
+    X.r1  = ~(L + X.ih);
+    X.low = L & 0x7FFFFFFFu;
+    return make_uint2((uint32_t)(sl >> 32), k | (j << 8));
+}
+
+// the same for any lane state: act = this lane codes a symbol at this step, eof = it is the EOF symbol (codec.rs:91-99:
+// high unchanged, encode_symbol); returns the message, shifts = k + j
+template <bool CB32>
+__device__ __forceinline__ uint2 chain_step_any(ChainState &X, uint32_t lo, uint32_t hi, uint32_t c, double rc, uint32_t sh,
+                                                bool act, bool eof, uint32_t &shifts)
+{
+    const uint32_t ihm = X.ih & 0x7FFFFFFFu;
+    const uint32_t R1  = (~(ihm + X.low)) >> sh;
+    const double   Y   = __builtin_fma((double)R1, rc, rc);
+    const uint32_t nlow   = X.low + (scale_div<false>(R1, Y, lo, c) << sh);
+    const uint32_t nihigh = eof ? ihm : ~(X.low + (scale_div<false, true>(R1, Y, eof ? 1u : hi, c) << sh) - 1u);
+    const uint32_t x      = ~(nlow ^ nihigh);
+    const uint32_t k      = x ? (uint32_t)__builtin_clz(x) : 32u;
+    const uint64_t sl     = (uint64_t)nlow << k;
+    const uint32_t low2   = (uint32_t)sl;
+    const uint32_t ih2    = (uint32_t)((uint64_t)nihigh << k);
+    const uint32_t t      = (low2 & ih2) << 1;
+    const uint32_t j      = (uint32_t)__builtin_clz(~t);
+    shifts = k + j;
+    if (act) {
+        X.low = (low2 << j) & 0x7FFFFFFFu;
+        X.ih  = (ih2 << j) & 0x7FFFFFFFu;
+        X.r1  = ~(X.ih + X.low);
+    }
+    return act ? make_uint2((uint32_t)(sl >> 32), k | (j << 8)) : make_uint2(0, 0);
+}
+
+// the bit-writer half of encode_symbol_spec (redux_coder.hpp): returns the length of the append
+template <int ST>
+__device__ __forceinline__ uint32_t emit_spec(EncState &S, uint32_t &nbm, uint32_t topk, uint32_t kj, uint8_t *wbase)
+{
+    const uint32_t k = kj & 0xFFu, j = kj >> 8;
+    const uint32_t P   = S.pend;
+    const uint32_t Pz  = k ? P : 0u;
+    const uint32_t km1 = k - 1u;
+    S.pend             = P - Pz + j;
+    const uint32_t m   = k + Pz;
+    uint32_t       run;
+    asm("v_bfm_b32 %0, %1, %2" : "=v"(run) : "v"(Pz), "v"(km1));
+    const uint64_t sa = S.acc << (m & 63u);
+    S.acc = (sa & 0xFFFFFFFF00000000ull) | (uint32_t)((uint32_t)sa + topk + run);
+    const uint32_t nb = nbm + m;
+    if ((int32_t)nb >= 0) {
+        *reinterpret_cast<uint32_t *>(wbase + S.off) = stream_dword<ST>((uint32_t)(S.acc >> (nb & 63u)));
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(S.off) : "i"(stride_of<ST>) : "memory");
+    }
+    nbm = nb | 0xFFFFFFE0u;
+    return m;
+}
+
+// the bit-writer half of encode_symbol: any pending count, every store checked against `limit`
+template <int ST>
+__device__ __forceinline__ void emit_careful(EncState &S, uint32_t topk, uint32_t kj, uint8_t *wbase, uint32_t limit)
+{
+    const uint32_t k = kj & 0xFFu, j = kj >> 8;
+    const uint32_t P  = S.pend;
+    const uint32_t Pz = k ? P : 0u;
+    S.pend            = P - Pz + j;
+    if (k + Pz <= 32) {
+        put_bits<ST>(S, topk + (((1u << (Pz & 31u)) - 1u) << ((k - 1u) & 31u)), k + Pz, wbase, limit);
+    } else {
+        const uint32_t b = topk >> (k - 1);
+        put_bits<ST>(S, b, 1, wbase, limit);
+        put_run<ST>(S, b ^ 1u, P, wbase, limit);
+        put_bits<ST>(S, topk & ((1u << (k - 1)) - 1u), k - 1, wbase, limit);
+    }
+}
+
+template <bool CB32>
+__global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pairs)
+{
+    __shared__ uint2 ring[kCoopRing / 8];
+    __shared__ uint2 fin[64]; // (low after the EOF symbol, its shifts): what encode_finish needs from the chain
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t blk0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t blk  = blk0 + lane;
+    const bool     live = blk < a.nblocks && !(a.table && a.table[blk].index == kIdleEntry);
+    const uint8_t *wsrc;
+    const EncLane  EL  = enc_lane(a, blk0, blk, lane, live, wsrc);
+    const uint32_t len = EL.len;
+    const uint32_t minlen = __builtin_amdgcn_readfirstlane(wave_min(live ? len : 0xFFFFFFFFu));
+    const uint32_t maxlen = __builtin_amdgcn_readfirstlane(wave_max(live ? len : 0u));
+    const uint32_t sh     = 32 - a.code_bits;
+    const rc_ptr   rc     = (rc_ptr)a.rc;
+    const uint64_t lives  = __builtin_amdgcn_ballot_w64(live);
+    if (lives == 0)
+        return;
+    uint32_t main_end = 0;
+    if (minlen > 16)
+        main_end = (minlen - 1) & ~15u;
+    const uint32_t nperiods = (maxlen + 1 + kPeriod - 1) / kPeriod; // symbols 0 .. maxlen (the longest block's EOF)
+    auto slot = [&](uint32_t i) { return ring + ((i >> 1) * 128u + lane * 2u); }; // symbols i (even) and i + 1 of this lane, i < 2 kPeriod
+
+    if (wave == 0) {
+        // ---------------- chain wave ----------------
+        // a lane without a block runs the lock-step part on a copy of the wave's first live block (valid pairs: its own
+        // column of the workspace was never written) and sends empty messages after it
+        const uint32_t col  = live ? lane : (uint32_t)__builtin_ctzll(lives);
+        const uint64_t gcol = (uint64_t)blockIdx.x * (a.block_size + kCoopSlack) * 64;
+        const uint2   *pg   = pairs + gcol + col;
+        auto load16 = [&](uint2 (&d)[16], uint32_t p) { // (up to 47 symbols past main_end: inside the slack)
+            const uint2 *q = pg + (uint64_t)p * 64;
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                d[i] = q[i * 64];
+        };
+        ChainState X;
+        X.low = 0; X.ih = 0; X.r1 = 0xFFFFFFFFu;
+        uint2 nx[16], nn[16];
+        if (main_end) {
+            load16(nx, 0);
+            load16(nn, 16);
+        }
+        const uint2 *pt = pairs + gcol + lane;
+        for (uint32_t t = 0; t < nperiods; t++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t p = t * kPeriod + 16 * h, ro = (t & 1) * kPeriod + 16 * h;
+                if (p + 16 <= main_end) {
+                    uint2 cur[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        cur[i] = nx[i];
+                        nx[i]  = nn[i];
+                    }
+                    load16(nn, p + 32);
+                    double r[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        r[i] = rc[p + i];
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) {
+                        const uint2 m0 = chain_step<CB32>(X, cur[i].x, cur[i].y, 257u + p + i, r[i], sh);
+                        const uint2 m1 = chain_step<CB32>(X, cur[i + 1].x, cur[i + 1].y, 258u + p + i, r[i + 1], sh);
+                        *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+                    }
+                } else {
+#pragma unroll 1
+                    for (uint32_t i = 0; i < 16; i += 2) {
+                        uint2 m[2];
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            const uint32_t q   = p + i + e;
+                            const bool     act = live && q <= len, eof = q == len;
+                            const uint2    lh  = (live && q < len) ? pt[(uint64_t)q * 64] : make_uint2(0, 1);
+                            const uint32_t qc  = q < maxlen ? q : maxlen; // (the reciprocal table ends at maxlen + slack)
+                            uint32_t       shifts;
+                            m[e] = chain_step_any<CB32>(X, eof ? 256u + q : lh.x, lh.y, 257u + qc, rc[qc], sh, act, eof, shifts);
+                            if (act && eof)
+                                fin[lane] = make_uint2(X.low, shifts);
+                        }
+                        *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m[0].x, m[0].y, m[1].x, m[1].y);
+                    }
+                }
+            }
+            pair_barrier();
+        }
+        return;
+    }
+
+    // ---------------- emit wave ----------------
+    uint8_t       *wdst  = a.slots + (uint64_t)blockIdx.x * (64 * a.slot_bytes + 128);
+    const uint32_t off0  = lane * 4u;
+    const uint32_t limit = off0 + (a.slot_cap / 4u) * 256u;
+    constexpr uint32_t kChunkBudget = (16 * 4 + 32) * (stride_of<kPairStride> / 4);
+    EncState S;
+    enc_init(S, off0);
+    for (uint32_t t = 0; t < nperiods; t++) {
+        pair_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t p = t * kPeriod + 16 * h, ro = (t & 1) * kPeriod + 16 * h;
+            uint2 msg[16];
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const uint4 two = *reinterpret_cast<const uint4 *>(slot(ro + i));
+                msg[i]     = make_uint2(two.x, two.y);
+                msg[i + 1] = make_uint2(two.z, two.w);
+            }
+            const bool fast = p + 16 <= main_end && __builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit) == 0;
+            if (fast) {
+                // eight symbols straight-line; the rare append of more than 32 bits only raises a flag, and the eight
+                // are then redone from the saved state with the general routine (as coder_chunk, redux_encode.hpp)
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const EncState S0  = S;
+                    uint32_t       nbm = S.nb - 32u, mx = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const uint32_t m = emit_spec<kPairStride>(S, nbm, msg[8 * g + i].x, msg[8 * g + i].y, wdst);
+                        mx = m > mx ? m : mx;
+                    }
+                    S.nb = nbm + 32u;
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > 32u) != 0, 0)) {
+                        S = S0;
+#pragma unroll
+                        for (int i = 0; i < 8; i++)
+                            emit_careful<kPairStride>(S, msg[8 * g + i].x, msg[8 * g + i].y, wdst, 0xFFFFFFFFu);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (uint32_t i = 0; i < 16; i++) {
+                    uint2 mg = msg[0];
+#pragma unroll
+                    for (int k = 1; k < 16; k++)
+                        mg = i == (uint32_t)k ? msg[k] : mg;
+                    const uint32_t q = p + i;
+                    if (q < main_end || (live && q <= len)) // (below main_end dead lanes code their copy, in step with the chain wave)
+                        emit_careful<kPairStride>(S, mg.x, mg.y, wdst, limit);
+                    if (live && q == len) {
+                        const uint2 f = fin[lane];
+                        S.low         = f.x;
+                        const uint32_t size = encode_finish<kPairStride>(S, f.y, a.code_bits, off0, wdst, limit);
+                        a.sizes[EL.ob]  = size;
+                        a.status[EL.ob] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+                    }
+                }
+            }
+        }
+    }
+}
+
+} // namespace redux

@@ -5,6 +5,7 @@
 //   redux_encode.hpp   k_fill_rc, k_encode, k_encode_pair (default encoder)
 //   redux_decode.hpp   k_decode, k_decode_lock (default decoder)
 //   redux_pack.hpp     k_scan_sizes, k_compact: slots -> dense stream + offsets
+//   redux_coop.hpp     k_coop_model, k_coop_chain: small grids, a block's model computed by 64 lanes
 //   redux_any.hpp      general Parameters (symbol_bits <= 16, code_bits <= 63), one lane per block
 //   redux_gen.hpp      k_encode_gen / k_decode_gen: 4- and 12-bit symbols (code_bits <= 32) in lock-step form
 //   redux_synth.hpp    k_gen_iid / k_gen_zipf
@@ -20,6 +21,7 @@
 #include "redux_decode.hpp"
 #include "redux_decode_adaptive.hpp"
 #include "redux_pack.hpp"
+#include "redux_coop.hpp"
 #include "redux_synth.hpp"
 #include "redux_static.hpp"
 
@@ -114,8 +116,9 @@ struct Geometry {
     bool     any;        // general-parameter path (redux_any.hpp): symbol_bits != 8 or code_bits > 32
     bool     gen;        // ... except 4- and 12-bit symbols with code_bits <= 32: lock-step kernels of redux_gen.hpp
     uint64_t tree_bytes; // any / gen (12-bit symbols): per-block tree in the workspace
+    bool     coop;       // small grid: k_coop_model + k_coop_chain (redux_coop.hpp), (low, high) pairs in the workspace
     // workspace layout (encode)
-    uint64_t off_rc, off_sizes, off_mode, off_slots, off_trees, total;
+    uint64_t off_rc, off_sizes, off_mode, off_slots, off_trees, off_pairs, total;
 };
 
 static int check_params(const redux_params *p)
@@ -225,7 +228,11 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.off_slots = g.off_mode + 256 + kClaimWords * 4; // mode word, then k_encode_pair's role book
     // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode
     g.off_trees = align_up(g.off_slots + ((g.nblocks + 63) / 64 * 64 + 1) * g.slot_bytes + (g.nblocks + 63) / 64 * 128, 256);
-    g.total     = g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes; // gen: whole waves
+    g.off_pairs = align_up(g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes, 256); // gen: whole waves
+    // a grid that leaves most SIMDs idle: the model by 64 lanes per block, the chain by one (u16 nodes, no freeze inside a block)
+    g.coop = !static_model && !g.any && !g.gen && g.u16 && !g.fixup && g.nblocks <= kCoopMaxBlocks && block_size >= kCoopMinBlock &&
+             g.nfreeze >= block_size && 64ull * g.slot_bytes < (1ull << 32);
+    g.total = g.off_pairs + (g.coop ? (g.nblocks + 63) / 64 * 64 * ((uint64_t)block_size + kCoopSlack) * 8 : 0);
     return g;
 }
 
@@ -257,7 +264,7 @@ static uint32_t cu_count()
 
 // ---- which kernel a call runs: ONE decision, used by the launch code and reported by
 // redux_encode_kernel_name / redux_decode_kernel_name (bench.py's roofline.kernel) ------------
-enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Gen4, Gen12, Any };
+enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Gen4, Gen12, Any, CoopCb32, Coop };
 enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Gen4, Gen12, Any };
 
 // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset; otherwise
@@ -273,6 +280,13 @@ static EncKernel pick_encode_kernel(const Geometry &g, const redux_params *p, bo
         return p->symbol_bits == 4 ? EncKernel::Gen4 : EncKernel::Gen12;
     if (g.any)
         return EncKernel::Any;
+    bool coop = g.coop;
+#ifdef REDUX_AB // A/B timing builds only: REDUX_ENCODE_KERNEL=pair keeps small grids on the pair kernel
+    if (getenv("REDUX_ENCODE_KERNEL"))
+        coop = false;
+#endif
+    if (coop)
+        return p->code_bits == 32 ? EncKernel::CoopCb32 : EncKernel::Coop;
     bool pair = g.u16 && aligned16 && encode_lanes(g, block_size) == 64;
 #ifdef REDUX_AB // A/B timing builds only: REDUX_ENCODE_KERNEL=single pins the one-wave kernel
     const char *force = getenv("REDUX_ENCODE_KERNEL");
@@ -327,6 +341,8 @@ const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, ui
     const Geometry g = geometry(p, in_len, block_size);
     const bool aligned16 = (((uintptr_t)d_in) & 15) == 0 && (block_size & 15) == 0;
     switch (pick_encode_kernel(g, p, aligned16, block_size)) {
+    case EncKernel::CoopCb32: return "k_coop_model + k_coop_chain<true> (small grid: model by 64 lanes per block, chain by one, code_bits 32)";
+    case EncKernel::Coop: return "k_coop_model + k_coop_chain<false> (small grid: model by 64 lanes per block, chain by one)";
     case EncKernel::PairCb32: return "k_encode_pair<false, true> (u16 tree, model wave + coder wave, code_bits 32)";
     case EncKernel::Pair: return "k_encode_pair<false, false> (u16 tree, model wave + coder wave)";
     case EncKernel::SingleU16: return "k_encode<true, false> (u16 tree, one wave per 64 blocks)";
@@ -406,9 +422,13 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
         return st;
     if (block_size == 0 || !d_workspace || !d_block_status || (in_len && !d_in))
         return REDUX_INVALID_INPUT;
-    const Geometry g = d_table ? geometry(p, tbl_blocks * (uint64_t)block_size, block_size) : geometry(p, in_len, block_size);
+    Geometry g = d_table ? geometry(p, tbl_blocks * (uint64_t)block_size, block_size) : geometry(p, in_len, block_size);
     if (d_table && (g.gen || g.any || in_len > 0xFFFFFFFFull || tbl_blocks == 0)) // lane offsets into d_in are 32-bit
         return tbl_blocks == 0 ? REDUX_INVALID_INPUT : REDUX_UNSUPPORTED;
+    if (g.coop && workspace_bytes < g.total) { // a workspace sized for a larger input (which has no pairs area): the pair kernel
+        g.coop  = false;
+        g.total = g.off_pairs;
+    }
     if (workspace_bytes < g.total)
         return REDUX_OUTPUT_TOO_SMALL;
     if (((uintptr_t)d_workspace) & 255)
@@ -484,9 +504,19 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
     const EncKernel which = pick_encode_kernel(g, p, a.aligned16 != 0, block_size);
     // what the pair kernel leaves in the slots (CompactArgs::mode): byte 0x01 -> row-major group
     // areas, 0x02 -> linear slots whose dwords are byte-reversed
-    if (which == EncKernel::PairCb32 || which == EncKernel::Pair)
+    if (which == EncKernel::PairCb32 || which == EncKernel::Pair || which == EncKernel::CoopCb32 || which == EncKernel::Coop)
         HIP_TRY(hipMemsetAsync(ws + g.off_mode, 1 | 2, 4, s));
     switch (which) {
+    case EncKernel::CoopCb32:
+    case EncKernel::Coop: {
+        uint2 *pairs = (uint2 *)(ws + g.off_pairs);
+        k_coop_model<<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
+        if (which == EncKernel::CoopCb32)
+            k_coop_chain<true><<<grid, 128, 0, s>>>(a, pairs);
+        else
+            k_coop_chain<false><<<grid, 128, 0, s>>>(a, pairs);
+        break;
+    }
     case EncKernel::PairCb32: k_encode_pair<false, true><<<grid, 128, 0, s>>>(a); break;
     case EncKernel::Pair: k_encode_pair<false, false><<<grid, 128, 0, s>>>(a); break;
     case EncKernel::SingleU16: k_encode<true, false><<<grid, 64, 0, s>>>(a); break;
@@ -513,7 +543,7 @@ static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *
 {
     if (!d_workspace || !d_block_status || !d_out_offsets || !d_out)
         return REDUX_INVALID_INPUT;
-    if (workspace_bytes < g.total)
+    if (workspace_bytes < g.off_pairs) // (the compaction reads nothing behind the slots and trees: a workspace without the pairs area will do)
         return REDUX_OUTPUT_TOO_SMALL;
     hipStream_t s  = (hipStream_t)stream;
     uint8_t    *ws = (uint8_t *)d_workspace;
