@@ -170,6 +170,7 @@ __device__ __forceinline__ uint2 chain_step(ChainState &X, uint32_t lo, uint32_t
     const uint32_t sh = CB32 ? 0u : sh_;
     const uint32_t R1 = X.r1 >> sh;
     const double   Y  = __builtin_fma((double)R1, rc, rc);
+    asm volatile("" : "+v"(hi)); // (the high half of an 8-byte load: keeps ISel from converting it as u64 >> 32, +1 v_add_f64; see coder_chunk)
     const uint32_t nlow   = X.low + (scale_div<false>(R1, Y, lo, c) << sh);
     const uint32_t nihigh = 0u - (X.low + (scale_div<false, true>(R1, Y, hi, c) << sh));
     const uint32_t x      = ~(nlow ^ nihigh);
@@ -287,7 +288,7 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
         const uint32_t col  = live ? lane : (uint32_t)__builtin_ctzll(lives);
         const uint64_t gcol = (uint64_t)blockIdx.x * (a.block_size + kCoopSlack) * 64;
         const uint2   *pg   = pairs + gcol + col;
-        auto load16 = [&](uint2 (&d)[16], uint32_t p) { // (up to 47 symbols past main_end: inside the slack)
+        auto load16 = [&](uint2 (&d)[16], uint32_t p) { // (up to 47 symbols past the last chunk: inside the slack)
             const uint2 *q = pg + (uint64_t)p * 64;
 #pragma unroll
             for (int i = 0; i < 16; i++)
@@ -295,24 +296,27 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
         };
         ChainState X;
         X.low = 0; X.ih = 0; X.r1 = 0xFFFFFFFFu;
-        uint2 nx[16], nn[16];
-        if (main_end) {
-            load16(nx, 0);
-            load16(nn, 16);
-        }
-        const uint2 *pt = pairs + gcol + lane;
-        for (uint32_t t = 0; t < nperiods; t++) {
+        // Chunks of 16 symbols; the pairs of chunk c + 2 are requested when chunk c starts (three register buffers whose
+        // roles rotate: the loop is unrolled by three so that no copy -- which would wait for the newest loads -- moves
+        // them).  Every chunk is loaded without a lane predicate (a short block's column is garbage behind its end, the
+        // slack keeps the addresses inside the area); what a lane does with a symbol is decided below.
+        const uint32_t nchunks = 2 * nperiods;
+        uint2 buf[3][16];
+        load16(buf[0], 0);
+        load16(buf[1], 16);
+        for (uint32_t c0 = 0; c0 < nchunks; c0 += 3) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t p = t * kPeriod + 16 * h, ro = (t & 1) * kPeriod + 16 * h;
+            for (int u = 0; u < 3; u++) {
+                const uint32_t c = c0 + u;
+                if (c >= nchunks)
+                    break;
+                const uint32_t p = 16 * c, ro = (c & 3u) * 16u;
+                uint2 (&cur)[16] = buf[u];
+                load16(buf[(u + 2) % 3], p + 32);
+                // one wait for the whole chunk: the 32 loads issued since (this chunk's and the previous one's) may stay
+                // in flight (vmcnt(32); the lgkmcnt / expcnt fields all ones = no wait)
+                __builtin_amdgcn_s_waitcnt(0x8F70);
                 if (p + 16 <= main_end) {
-                    uint2 cur[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        cur[i] = nx[i];
-                        nx[i]  = nn[i];
-                    }
-                    load16(nn, p + 32);
                     double r[16];
 #pragma unroll
                     for (int i = 0; i < 16; i++)
@@ -329,9 +333,12 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                         uint2 m[2];
 #pragma unroll
                         for (int e = 0; e < 2; e++) {
+                            uint2 lh = cur[0];
+#pragma unroll
+                            for (int k = 1; k < 16; k++)
+                                lh = i + e == (uint32_t)k ? cur[k] : lh;
                             const uint32_t q   = p + i + e;
                             const bool     act = live && q <= len, eof = q == len;
-                            const uint2    lh  = (live && q < len) ? pt[(uint64_t)q * 64] : make_uint2(0, 1);
                             const uint32_t qc  = q < maxlen ? q : maxlen; // (the reciprocal table ends at maxlen + slack)
                             uint32_t       shifts;
                             m[e] = chain_step_any<CB32>(X, eof ? 256u + q : lh.x, lh.y, 257u + qc, rc[qc], sh, act, eof, shifts);
@@ -341,8 +348,9 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                         *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m[0].x, m[0].y, m[1].x, m[1].y);
                     }
                 }
+                if (c & 1u)
+                    pair_barrier();
             }
-            pair_barrier();
         }
         return;
     }

@@ -1234,3 +1234,59 @@ def test_12_bit_decoder_on_a_large_grid_uses_workspace_trees(rx):
     assert (sizes[:-1] == keep).all()
     got = dec.reshape(nb, bs)[:, :keep]
     assert (got[:-1] == data[: (nb - 1) * bs].reshape(nb - 1, bs)[:, :keep]).all()
+
+
+def test_small_grid_kernels_on_a_hand_made_table(rx):
+    """The small-grid encoder (redux_coop.hpp: a block's model by 64 lanes, chain and bit writer as two waves) on what
+    redux_block_table_v never produces: idle entries in FRONT of a wave's blocks, and blocks from 1 to 65,536 bytes in the
+    same wave (so the lock-step part is short and thousands of symbols run on the per-lane path).  Every stream equals the
+    oracle's; the kernel names say which launches take this path."""
+    import ctypes as C
+    import torch
+    from redux_amd import _lib
+    L = _lib.lib()
+    BS = 65536
+    for w in ((8, 30, 32), (8, 20, 24)):
+        cp = _lib.Params(*w)
+        assert b"k_coop_model" in L.redux_encode_kernel_name(C.byref(cp), None, 62 * BS, BS)
+        assert b"k_encode_pair" in L.redux_encode_kernel_name(C.byref(cp), None, 2048 * BS, BS)
+        rng = np.random.default_rng(sum(w))
+        lens = [BS, 1, 40000, BS - 1, 63, 64, 65, 1024, 17, BS, 30000, 2, 33, 5000, 0, 16]
+        datas = [bytes((rng.integers(0, 256, n, dtype=np.uint8) >> rng.integers(0, 6)).tolist()) for n in lens]
+        offs_in, pos = [], 0
+        for d in datas:
+            offs_in.append(pos)
+            pos += (len(d) + 15) & ~15
+        total_in = pos + 16
+        packed = np.zeros(total_in, dtype=np.uint8)
+        for o, d in zip(offs_in, datas):
+            packed[o: o + len(d)] = np.frombuffer(d, dtype=np.uint8)
+        nb = len(lens)
+        # wave 0: three idle entries, then blocks 0..7 in a shuffled order; wave 1: one idle entry, blocks 8..15, idle entries to the end
+        order0, order1 = [5, 0, 7, 2, 1, 6, 3, 4], [15, 8, 14, 9, 13, 10, 12, 11]
+        tab = np.zeros(128, dtype=rx.BLOCK_DTYPE)
+        tab["index"] = rx.BLOCK_IDLE
+        for slot, b in list(zip(range(3, 11), order0)) + list(zip(range(65, 73), order1)):
+            tab[slot] = (offs_in[b], lens[b], b)
+        ne = len(tab)
+        d_in = torch.from_numpy(packed).cuda()
+        d_tab = torch.from_numpy(tab.view(np.uint8).copy()).cuda()
+        wsb = L.redux_encode_workspace_bytes(C.byref(cp), ne * BS, BS)
+        cap = nb * L.redux_encode_slot_bytes(C.byref(cp), BS)
+        ws = torch.empty(wsb + 256, dtype=torch.uint8, device="cuda")
+        wsp = ws.data_ptr() + (-ws.data_ptr()) % 256
+        d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        d_offs = torch.zeros(nb + 1, dtype=torch.int64, device="cuda")
+        d_st = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        d_sum = torch.zeros(2, dtype=torch.int32, device="cuda")
+        strm = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        r = L.redux_encode_blocks_v_dev(C.byref(cp), C.c_void_p(d_in.data_ptr()), total_in, C.c_void_p(d_tab.data_ptr()), ne, nb, BS, 1,
+                                        C.c_void_p(d_out.data_ptr()), cap, C.c_void_p(d_offs.data_ptr()), C.c_void_p(d_st.data_ptr()),
+                                        C.c_void_p(d_sum.data_ptr()), C.c_void_p(wsp), wsb, strm)
+        torch.cuda.synchronize()
+        assert r == 0 and d_sum.tolist() == [0, 0]
+        offs = d_offs.cpu().numpy().astype(np.uint64)
+        out = d_out.cpu().numpy()
+        for b, d in enumerate(datas):
+            want, _ = ox.compress(d, w)
+            assert out[int(offs[b]): int(offs[b + 1])].tobytes() == want, (w, b, len(d))

@@ -18,7 +18,7 @@ def measure():
     from redux_amd import _lib
     import ctypes as C
     block = 65536
-    for nb in (1, 16, 62, 64, 256, 1024, 2048):
+    for nb in [int(x) for x in os.environ.get("SMALL_GRID_BLOCKS", "1,16,62,64,256,1024,2048").split(",")]:
         n = nb * block
         d_in = rx.gen_zipf(n)
         enc = rx.DeviceEncoder((8, 30, 32), block, n)
@@ -34,15 +34,17 @@ def measure():
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
-        assert summ.tolist() == [0, 0]
-        total = int(offs[nb].item())
-        d_out, sizes, dst, dsum = dec.decode(out[:total], offs)
-        torch.cuda.synchronize()
-        assert torch.equal(d_out[:n], d_in)
+        verify = not os.environ.get("SMALL_GRID_NOVERIFY")  # (timing-only variants whose output is invalid)
+        if verify:
+            assert summ.tolist() == [0, 0]
+            total = int(offs[nb].item())
+            d_out, sizes, dst, dsum = dec.decode(out[:total], offs)
+            torch.cuda.synchronize()
+            assert torch.equal(d_out[:n], d_in)
         cp = _lib.Params(8, 30, 32)
         name = _lib.lib().redux_encode_kernel_name(C.byref(cp), C.c_void_p(d_in.data_ptr()), n, block).decode()
         print(json.dumps({"blocks": nb, "encode_ms": round(sorted(ts)[2], 3), "MBps": round(n / sorted(ts)[2] / 1e3, 1),
-                          "kernel": name.split(" (")[0], "roundtrip": True}), flush=True)
+                          "kernel": name.split(" (")[0], "roundtrip": verify}), flush=True)
 
 
 if __name__ == "__main__":
