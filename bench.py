@@ -24,6 +24,9 @@ Extra objects on the JSON line:
                 prefix of the same workload, on this box's host cores, rank 0 at N=1 only.
   decode        (rank 0, after the timed steps, not part of `value`) one timed pass of the
                 decoder over the dense output, checked equal to the input on the device.
+  small_launch  (rank 0 at N=1, not part of `value`) encode and decode of the first 62 blocks
+                alone -- a launch where one block's serial chain is the whole time; its streams
+                are checked equal to the same blocks' streams of the full launch.
 """
 import argparse
 import json
@@ -273,6 +276,33 @@ def main():
                           "MBps": round(n / (dms * 1e-3) / 1e6, 1),
                           "algorithmic_GBps": round(algo_bytes / (dms * 1e-3) / 1e9, 2),
                           "frac": round(algo_bytes / (dms * 1e-3) / HBM_PEAK, 5), "issue": dissue, "roundtrip_equal": True}
+
+    if world == 1 and not args.no_decode:
+        # Small launch (rank 0, N = 1, not part of `value`): 62 blocks of the same workload -- a 4 MiB file at this block size --
+        # where the serial chain of ONE block is the whole time.  The encoder is the small-grid path (redux_coop.hpp).
+        sb = min(62, nblocks)
+        sn = sb * BLOCK
+        senc = rx.DeviceEncoder(PARAMS, BLOCK, sn, device=dev)
+        sdec = rx.DeviceDecoder(PARAMS, BLOCK, sb, device=dev)
+        s_in = d_in[:sn]
+        for _ in range(2):
+            s_out, s_offs, s_st, s_sum = senc.encode(s_in)
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        stotal = int(s_offs[sb].item())
+        sdec.decode(s_out[:stotal], s_offs)
+        torch.cuda.synchronize()
+        e0.record()
+        s_out, s_offs, s_st, s_sum = senc.encode(s_in)
+        e1.record()
+        sd_out, _, _, sd_sum = sdec.decode(s_out[:stotal], s_offs)
+        e2.record()
+        torch.cuda.synchronize()
+        assert s_sum.tolist() == [0, 0] and sd_sum.tolist() == [0, 0] and torch.equal(sd_out[:sn], s_in)
+        assert torch.equal(s_out[:stotal], enc.out[:stotal]), "small-grid kernels and the full-grid kernel differ on the same blocks"
+        line["small_launch"] = {"blocks": sb, "encode_ms": round(e0.elapsed_time(e1), 3), "decode_ms": round(e1.elapsed_time(e2), 3),
+                                "encode_kernel": _lib.lib().redux_encode_kernel_name(C.byref(cp), C.c_void_p(s_in.data_ptr()), sn, BLOCK).decode().split(" (")[0],
+                                "equal_to_full_grid_streams": True}
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import cbind as ox

@@ -15,7 +15,7 @@
 //
 // The pairs are stored symbol-major per group of 64 blocks, pairs[(group * (block_size + slack) + i) * 64 + lane], so the chain
 // wave reads 512 contiguous bytes per symbol.  Chosen by geometry() (redux_hip.hip) for launches of at most
-// kCoopMaxBlocks blocks whose model neither freezes inside a block nor needs u32 nodes; results are the same bytes
+// kCoopMaxBlocks slots of u16-node blocks (a model that freezes inside a block included); results are the same bytes
 // as every other kernel's (tests/test_gpu_parity.py: the corpus and batch tests run on it).
 //
 // Included by redux_hip.hip (one translation unit).
@@ -29,7 +29,7 @@
 
 namespace redux {
 
-constexpr uint64_t kCoopMaxBlocks = 1024; // (the pairs take 8 bytes per input byte of workspace: 512 MiB at 1024 x 64 KiB)
+constexpr uint64_t kCoopMaxBlocks = 2048; // slots, idle table entries included (the pairs take 8 bytes per input byte of workspace: 1 GiB at 2048 x 64 KiB)
 constexpr uint32_t kCoopMinBlock  = 1024; // shorter blocks: the per-block set-up (scan, tree build) outweighs the model
 constexpr uint32_t kCoopSlack     = 64;   // symbols of slack behind a group's pairs (the chain wave prefetches unclamped)
 
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
             for (int i = 0; i < 16; i++) {
                 const uintptr_t ad = C0 + 16 * (uintptr_t)k + i;
                 const uint32_t  s  = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                if (k < npieces && ad >= A0 && ad < A1)
+                if (k < npieces && ad >= A0 && ad < A1 && (uint32_t)(ad - (uintptr_t)src) < a.nfreeze) // (the model stops counting at the freeze, adaptive_tree.rs:84)
                     T.add((((s + 1u) & 255u) << Tree<true>::kShift) | T.L, T.inc);
             }
         }
@@ -129,10 +129,11 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
                 const uintptr_t ad = C0 + 16 * (uintptr_t)k + i;
                 const uint32_t  s  = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
                 if (k < npieces && ad >= A0 && ad < A1) {
-                    const uint32_t q = (uint32_t)(ad - (uintptr_t)src); // symbols (= updates) before this one
+                    const uint32_t q   = (uint32_t)(ad - (uintptr_t)src); // symbols before this one
+                    const uint32_t nup = q < a.nfreeze ? q : a.nfreeze;     // updates before this one
                     uint32_t       lo, hi;
                     // (the update of a block's last symbol is unobservable and skipped: u16 nodes, Tree)
-                    T.template get_frequency<true>(s, q, q + 1 != len, lo, hi);
+                    T.template get_frequency<true>(s, nup, q < a.nfreeze && q + 1 != len, lo, hi);
                     pg[(uint64_t)q * 64] = make_uint2(lo, hi);
                 }
             }
@@ -272,6 +273,7 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
     const uint32_t maxlen = __builtin_amdgcn_readfirstlane(wave_max(live ? len : 0u));
     const uint32_t sh     = 32 - a.code_bits;
     const rc_ptr   rc     = (rc_ptr)a.rc;
+    const uint32_t nfreeze = a.nfreeze;
     const uint64_t lives  = __builtin_amdgcn_ballot_w64(live);
     if (lives == 0)
         return;
@@ -317,31 +319,31 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                 // in flight (vmcnt(32); the lgkmcnt / expcnt fields all ones = no wait)
                 __builtin_amdgcn_s_waitcnt(0x8F70);
                 if (p + 16 <= main_end) {
-                    double r[16];
+                    double   r[16];
+                    uint32_t nup[16]; // updates before symbol p + i (wave-uniform: scalar registers)
 #pragma unroll
-                    for (int i = 0; i < 16; i++)
-                        r[i] = rc[p + i];
+                    for (int i = 0; i < 16; i++) {
+                        nup[i] = p + i < nfreeze ? p + i : nfreeze;
+                        r[i]   = rc[nup[i]];
+                    }
 #pragma unroll
                     for (int i = 0; i < 16; i += 2) {
-                        const uint2 m0 = chain_step<CB32>(X, cur[i].x, cur[i].y, 257u + p + i, r[i], sh);
-                        const uint2 m1 = chain_step<CB32>(X, cur[i + 1].x, cur[i + 1].y, 258u + p + i, r[i + 1], sh);
+                        const uint2 m0 = chain_step<CB32>(X, cur[i].x, cur[i].y, 257u + nup[i], r[i], sh);
+                        const uint2 m1 = chain_step<CB32>(X, cur[i + 1].x, cur[i + 1].y, 257u + nup[i + 1], r[i + 1], sh);
                         *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m0.x, m0.y, m1.x, m1.y);
                     }
-                } else {
-#pragma unroll 1
-                    for (uint32_t i = 0; i < 16; i += 2) {
+                } else { // from the shortest block's last chunk on: what a lane does with a symbol is its own matter
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) {
                         uint2 m[2];
 #pragma unroll
                         for (int e = 0; e < 2; e++) {
-                            uint2 lh = cur[0];
-#pragma unroll
-                            for (int k = 1; k < 16; k++)
-                                lh = i + e == (uint32_t)k ? cur[k] : lh;
                             const uint32_t q   = p + i + e;
                             const bool     act = live && q <= len, eof = q == len;
-                            const uint32_t qc  = q < maxlen ? q : maxlen; // (the reciprocal table ends at maxlen + slack)
+                            const uint32_t qm  = q < maxlen ? q : maxlen;      // (the reciprocal table ends at min(maxlen, nfreeze) + slack)
+                            const uint32_t qc  = qm < nfreeze ? qm : nfreeze; // updates before symbol q
                             uint32_t       shifts;
-                            m[e] = chain_step_any<CB32>(X, eof ? 256u + q : lh.x, lh.y, 257u + qc, rc[qc], sh, act, eof, shifts);
+                            m[e] = chain_step_any<CB32>(X, eof ? 256u + qc : cur[i + e].x, cur[i + e].y, 257u + qc, rc[qc], sh, act, eof, shifts);
                             if (act && eof)
                                 fin[lane] = make_uint2(X.low, shifts);
                         }
@@ -374,7 +376,9 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                 msg[i]     = make_uint2(two.x, two.y);
                 msg[i + 1] = make_uint2(two.z, two.w);
             }
-            const bool fast = p + 16 <= main_end && __builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit) == 0;
+            // (a lane without a symbol at some step gets the empty message, which changes nothing: every chunk takes the
+            // straight-line path while the slots have room; a block's EOF tail is written after the group of eight that holds it)
+            const bool fast = __builtin_amdgcn_ballot_w64(S.off + kChunkBudget > limit) == 0;
             if (fast) {
                 // eight symbols straight-line; the rare append of more than 32 bits only raises a flag, and the eight
                 // are then redone from the saved state with the general routine (as coder_chunk, redux_encode.hpp)
@@ -393,6 +397,14 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
 #pragma unroll
                         for (int i = 0; i < 8; i++)
                             emit_careful<kPairStride>(S, msg[8 * g + i].x, msg[8 * g + i].y, wdst, 0xFFFFFFFFu);
+                    }
+                    const uint32_t pg = p + 8 * g;
+                    if (pg + 8 > main_end && live && len >= pg && len < pg + 8) { // this lane's EOF symbol was among the eight
+                        const uint2 f = fin[lane];
+                        S.low         = f.x;
+                        const uint32_t size = encode_finish<kPairStride>(S, f.y, a.code_bits, off0, wdst, limit);
+                        a.sizes[EL.ob]  = size;
+                        a.status[EL.ob] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
                     }
                 }
             } else {

@@ -229,9 +229,9 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode
     g.off_trees = align_up(g.off_slots + ((g.nblocks + 63) / 64 * 64 + 1) * g.slot_bytes + (g.nblocks + 63) / 64 * 128, 256);
     g.off_pairs = align_up(g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes, 256); // gen: whole waves
-    // a grid that leaves most SIMDs idle: the model by 64 lanes per block, the chain by one (u16 nodes, no freeze inside a block)
+    // a grid that leaves most SIMDs idle: the model by 64 lanes per block, the chain by one (u16 nodes)
     g.coop = !static_model && !g.any && !g.gen && g.u16 && !g.fixup && g.nblocks <= kCoopMaxBlocks && block_size >= kCoopMinBlock &&
-             g.nfreeze >= block_size && 64ull * g.slot_bytes < (1ull << 32);
+             64ull * g.slot_bytes < (1ull << 32);
     g.total = g.off_pairs + (g.coop ? (g.nblocks + 63) / 64 * 64 * ((uint64_t)block_size + kCoopSlack) * 8 : 0);
     return g;
 }

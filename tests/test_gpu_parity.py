@@ -1249,7 +1249,7 @@ def test_small_grid_kernels_on_a_hand_made_table(rx):
     for w in ((8, 30, 32), (8, 20, 24)):
         cp = _lib.Params(*w)
         assert b"k_coop_model" in L.redux_encode_kernel_name(C.byref(cp), None, 62 * BS, BS)
-        assert b"k_encode_pair" in L.redux_encode_kernel_name(C.byref(cp), None, 2048 * BS, BS)
+        assert b"k_encode_pair" in L.redux_encode_kernel_name(C.byref(cp), None, 4096 * BS, BS)
         rng = np.random.default_rng(sum(w))
         lens = [BS, 1, 40000, BS - 1, 63, 64, 65, 1024, 17, BS, 30000, 2, 33, 5000, 0, 16]
         datas = [bytes((rng.integers(0, 256, n, dtype=np.uint8) >> rng.integers(0, 6)).tolist()) for n in lens]

@@ -18,7 +18,7 @@ def measure():
     from redux_amd import _lib
     import ctypes as C
     block = 65536
-    for nb in [int(x) for x in os.environ.get("SMALL_GRID_BLOCKS", "1,16,62,64,256,1024,2048").split(",")]:
+    for nb in [int(x) for x in os.environ.get("SMALL_GRID_BLOCKS", "1,16,62,64,256,1024,2048,4096").split(",")]:
         n = nb * block
         d_in = rx.gen_zipf(n)
         enc = rx.DeviceEncoder((8, 30, 32), block, n)
