@@ -315,7 +315,20 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
         // the division chain of the next step's code value (codec.rs:131) starts under the rest of the commit
         uint32_t R1  = r1 >> sh;
         double   R1d = (double)R1, xd = R1d + 1.0, rinv = __builtin_amdgcn_rcp(xd);
-        for (; p + 16 <= pfast; p += 16) {
+        // The loop exists twice.  GEN == false: every step updates the model (p + 16 <= freeze point): constants pinned in
+        // registers, the count as an induction variable.  GEN == true: the steps from the freeze point on update nothing
+        // (adaptive_tree.rs:84) -- the count, its reciprocal and every addend are selected per step by the wave-uniform
+        // "this step still updates", so the turn that crosses the freeze point and all turns behind it stay in lock-step
+        // form instead of falling to the general loop below (a model of 14 frequency bits freezes after a quarter of a
+        // 64 KiB block).  The frozen reciprocal is read once.
+        // (only a model that freezes inside a block of this size has the second loop -- and a table that reaches its
+        // freeze point: geometry() sizes it min(block_size, freeze point) + 33 entries)
+        const bool   freezes = nfreeze < kAdFullValueSteps && nfreeze < a.block_size;
+        const f64x4  rcF4 = rcv[freezes ? nfreeze >> 2 : 0u];
+        const double rcF = (nfreeze & 3) == 0 ? rcF4.x : (nfreeze & 3) == 1 ? rcF4.y : (nfreeze & 3) == 2 ? rcF4.z : rcF4.w;
+        auto fast_loop = [&](auto gen_tag, const uint32_t pend) {
+        constexpr bool GEN = decltype(gen_tag)::value;
+        for (; p + 16 <= pend; p += 16) {
             if (__builtin_amdgcn_ballot_w64((int32_t)S.dflag >= 0) == 0)
                 break;
             uint32_t img[4] = {0, 0, 0, 0}; // this iteration's sixteen bytes
@@ -334,11 +347,21 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                         *reinterpret_cast<uint4 *>(dst + (p - 16)) = oq;
                 }
                 request();
-                rcn = rcv[((p + 4 * G) >> 2) + 1]; // the table has 32 entries of slack (geometry())
+                if (GEN) { // (the table ends 32 entries behind the freeze point)
+                    const uint32_t pg = p + 4 * G < nfreeze ? p + 4 * G : nfreeze;
+                    rcn = rcv[(pg >> 2) + 1];
+                } else
+                    rcn = rcv[((p + 4 * G) >> 2) + 1]; // the table has 32 entries of slack (geometry())
 #pragma unroll
                 for (int K = 0; K < 4; K++) {
-                    const double   rc = rcg[K];
-                    const uint32_t c  = 257u + p + 4 * G + K;
+                    const uint32_t idx = p + 4 * G + K;
+                    const bool     upd = !GEN || idx < nfreeze; // (wave-uniform) this step updates the model
+                    const double   rc  = upd ? rcg[K] : rcF;
+                    const uint32_t c   = 257u + (upd ? idx : nfreeze);
+                    // the update's constants: the pinned registers while every step updates, scalar selects otherwise
+                    const uint32_t u01010101 = GEN ? (upd ? 0x01010101u : 0u) : k01010101;
+                    const uint32_t u10001 = GEN ? (upd ? 0x10001u : 0u) : k10001, u10000 = GEN ? (upd ? 0x10000u : 0u) : k10000;
+                    const uint32_t u1 = GEN ? (upd ? 1u : 0u) : 1u;
 #define REDUX_AD_TAIL                                                                                                  \
     if (G != 0 || K != 0) {                                                                                            \
         const int PG = K == 0 ? G - 1 : G, PK = K == 0 ? 3 : K - 1; /* (constants once the loops are unrolled) */      \
@@ -398,7 +421,7 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                         uint32_t b3 = bits; // (an opaque copy: without it the kernel measures 0.5 % slower, one v_mov fewer or not)
                         asm volatile("" : "+v"(b3));
                         // byte k of t0 / t1 = 1 iff node k is incremented; each add takes its byte as an SDWA operand
-                        const uint32_t t0 = (kp0 >> b3) & k01010101, t1 = (kp1 >> b3) & k01010101;
+                        const uint32_t t0 = (kp0 >> b3) & u01010101, t1 = (kp1 >> b3) & u01010101;
 #define REDUX_AD_ADD_BYTE(n, t, B)                                                                                     \
     asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B : "+v"(n) : "v"(t));
                         REDUX_AD_ADD_BYTE(T.n128, t0, 0)
@@ -425,12 +448,18 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                     // ---- C's shadow: the B cell's update (+16 iff bit 4 clear, +8 iff bits 4 and 3 clear, +24 iff bit 4
                     // set and bit 3 clear), the factor both ends of the new interval share (codec.rs:133-134)
                     {
-                        const uint32_t t34 = (~m3 & k10000) | 1u;
-                        A.bump64(aB, ~m4 & t34, m4 & ~m3 & k10000);
+                        const uint32_t t34 = (~m3 & u10000) | u1;
+                        A.bump64(aB, ~m4 & t34, m4 & ~m3 & u10000);
                     }
                     double Y = __builtin_fma(R1d, rc, rc);
-                    cdm1     = cd;
-                    cd += 1.0;
+                    if (GEN) { // the next step's count: one more while this step updated
+                        const double inc = upd ? 1.0 : 0.0;
+                        cdm1 += inc;
+                        cd += inc;
+                    } else {
+                        cdm1 = cd;
+                        cd += 1.0;
+                    }
                     asm volatile("" : "+v"(Y), "+v"(cd));
                     REDUX_AD_FENCE();
                     // ---- D: levels 2-0 from the octet cell (+1 | +2, +3 | +4, +5 | +6, +7 | spare), narrowing and
@@ -466,8 +495,8 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                     // bit 2 clear); issued at the top of the next step
                     {
                         const uint32_t r0 = sym & 1u;
-                        t_lo  = ~m1 & k10001 & ~r0;
-                        t_hi  = (~m2 & k10000) | (m1 & ~r0 & 1u);
+                        t_lo  = ~m1 & u10001 & ~r0;
+                        t_hi  = (~m2 & u10000) | (m1 & ~r0 & u1);
                         t_aC  = aC | (m2 & 8u);
                         t_n   = n;
                         t_sym = sym;
@@ -530,6 +559,12 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
             oq.y = (int32_t)S.dflag >= 0 ? img[1] : oq.y;
             oq.z = (int32_t)S.dflag >= 0 ? img[2] : oq.z;
             oq.w = (int32_t)S.dflag >= 0 ? img[3] : oq.w;
+        }
+        };
+        fast_loop(std::false_type(), pfast);
+        if (freezes) {
+            p = __builtin_amdgcn_readfirstlane(p); // (uniform anyway; behind the first loop's exits the compiler no longer knows)
+            fast_loop(std::true_type(), capw);
         }
 #undef REDUX_AD_STEP
 #undef REDUX_AD_MASK
