@@ -89,6 +89,28 @@ struct GenTree {
         lo = ls;
         hi = hs + (m >> SB) * nup; // s + 1 == 2^SB selects the derived node 2^SB = 2^SB + #updates
     }
+    // the share of levels [B0, B1) in get_frequency(s): fetch-adds and masked sums of those levels only; the level-
+    // independent terms (s, s + 1, the derived node) ride with the share that starts at level 0.  The shares of a
+    // partition of the levels add up to get_frequency's (low, high).
+    template <int B0, int B1>
+    __device__ __forceinline__ void get_frequency_part(uint32_t s, uint32_t nup, bool upd, uint32_t &lo, uint32_t &hi) const
+    {
+        uint32_t       x[SB];
+        const uint32_t m = s + 1;
+#pragma unroll
+        for (int b = B0; b < B1; b++) {
+            const uint32_t e = (s | (1u << b)) & (kMask << b);
+            x[b]             = fetch_add(e, (upd && !((s >> b) & 1u)) ? 1u : 0u);
+        }
+        uint32_t ls = B0 == 0 ? s : 0u, hs = B0 == 0 ? m + (m >> SB) * nup : 0u;
+#pragma unroll
+        for (int b = B0; b < B1; b++) {
+            ls += ((s >> b) & 1u) ? x[b] : 0u;
+            hs += ((m >> b) & 1u) ? x[b] : 0u;
+        }
+        lo = ls;
+        hi = hs;
+    }
 };
 
 // symbol k of a block of `len` bytes at src: read_bits(SB) MSB-first
@@ -211,6 +233,113 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
             const uint32_t size   = encode_finish(S, shifts, a.code_bits, off0, wdst, limit);
             a.sizes[blk]  = size;
             a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+        }
+    }
+}
+
+// 12-bit symbols: the LDS holds 16 trees per CU, so a CU runs ONE workgroup and three of its SIMDs would idle.  The
+// same kernel as three waves on three SIMDs: waves 0 and 1 are the model, each for half of the tree's levels (symbol
+// load a step ahead, six of the twelve fetch-adds -- they are independent -- and their share of the two masked sums ->
+// a partial (low, high) into an LDS ring of its own), wave 2 the coder (adds the shares; interval narrowing,
+// renormalisation, bit output, EOF tail); a half of eight symbols is handed over per s_barrier, as in k_encode_pair.  A
+// step costs the longest of the three instead of their sum (8.6 -> 14 GB/s with one model wave, ... with two).  All
+// waves derive the same schedule from wave-uniform values.
+template <int SB>
+__global__ void __launch_bounds__(192) k_encode_gen_pair(GenEncArgs a)
+{
+    typedef GenTree<SB> Tree;
+    constexpr uint32_t kHalf = 8, kModelWaves = 2;
+    constexpr int      kSplit = SB / 2;
+    __shared__ uint32_t lds[Tree::kDwords];
+    __shared__ uint2    ring[kModelWaves][2 * kHalf * 64];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t blk0 = (uint64_t)blockIdx.x * Tree::kBlocks;
+    const uint64_t blk  = blk0 + lane;
+    const bool     live = lane < Tree::kBlocks && blk < a.nblocks;
+    for (uint32_t i = threadIdx.x; i < Tree::kDwords / 4; i += 192)
+        reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    uint32_t len = 0;
+    if (live) {
+        const uint64_t rem = a.in_len - blk * a.block_size;
+        len                = rem < a.block_size ? (uint32_t)rem : a.block_size;
+    }
+    const uint32_t nsym    = (uint32_t)(((uint64_t)len * 8) / SB); // whole symbols; trailing bits are dropped (codec.rs:108)
+    const uint32_t maxsym  = __builtin_amdgcn_readfirstlane(wave_max(live ? nsym : 0u));
+    const uint32_t nfreeze = a.nfreeze;
+    const uint32_t nper    = (maxsym + 1 + kHalf - 1) / kHalf; // symbols 0 .. maxsym (the longest block's EOF)
+    constexpr uint32_t kCount0 = (1u << SB) + 1u;
+
+    if (wave < kModelWaves) {
+        // ---------------- model waves ----------------
+        Tree T;
+        T.init(lds, lane);
+        const uint8_t *src      = a.in + (live ? blk : blk0) * (uint64_t)a.block_size;
+        const uint32_t last_sym = nsym ? nsym - 1u : 0u;
+        const bool     can_load = live && nsym != 0;
+        const uint8_t *psrc     = can_load ? src : reinterpret_cast<const uint8_t *>(a.rc); // (always mapped, at least 33 doubles)
+        uint32_t       raw_next = gen_symbol_load<SB>(psrc, 0), k_next = 0;
+        uint2         *my       = ring[wave];
+        for (uint32_t t = 0; t < nper; t++) {
+#pragma unroll
+            for (uint32_t i = 0; i < kHalf; i++) {
+                const uint32_t p   = t * kHalf + i;
+                const uint32_t nup = p < nfreeze ? p : nfreeze; // wave-uniform
+                const uint32_t sym = gen_symbol_decode<SB>(raw_next, k_next);
+                {
+                    const uint32_t q = p + 1 < last_sym ? p + 1 : last_sym;
+                    k_next           = can_load ? q : 0u;
+                    raw_next         = gen_symbol_load<SB>(psrc, k_next);
+                }
+                uint32_t lo = 0, hi = 0;
+                if (live && p < nsym) {
+                    if (wave == 0)
+                        T.template get_frequency_part<0, kSplit>(sym, nup, p < nfreeze, lo, hi);
+                    else
+                        T.template get_frequency_part<kSplit, SB>(sym, nup, p < nfreeze, lo, hi);
+                }
+                my[((t & 1u) * kHalf + i) * 64 + lane] = make_uint2(lo, hi);
+            }
+            pair_barrier();
+        }
+        return;
+    }
+    // ---------------- coder wave ----------------
+    uint8_t       *wdst  = a.slots + blk0 * a.slot_bytes;
+    const uint32_t off0  = live ? lane * (uint32_t)a.slot_bytes : 0u; // (dead lanes store nothing: everything below is predicated)
+    const uint32_t limit = off0 + a.slot_cap;
+    const uint32_t sh    = 32 - a.code_bits;
+    const rc_ptr   rc    = (rc_ptr)a.rc;
+    EncState S;
+    enc_init(S, off0);
+    for (uint32_t t = 0; t < nper; t++) {
+        pair_barrier();
+        uint2 lh[kHalf];
+#pragma unroll
+        for (uint32_t i = 0; i < kHalf; i++) {
+            const uint2 p0 = ring[0][((t & 1u) * kHalf + i) * 64 + lane], p1 = ring[1][((t & 1u) * kHalf + i) * 64 + lane];
+            lh[i] = make_uint2(p0.x + p1.x, p0.y + p1.y);
+        }
+        // (count <= 2^SB + 1 + 65535 < 2^17 for the u16 trees: the quotients need no fix-up, scale_div)
+        constexpr bool kFix = (1u << SB) + 1u + Tree::kMaxSymbols >= (1u << 17);
+#pragma unroll
+        for (uint32_t i = 0; i < kHalf; i++) {
+            const uint32_t p   = t * kHalf + i;
+            const uint32_t nup = p < nfreeze ? p : nfreeze;
+            const double   r   = rc[nup];
+            const uint32_t c   = kCount0 + nup;
+            const uint2    e   = lh[i];
+            if (live && p < nsym) {
+                encode_symbol<kFix>(S, e.x, e.y, c, r, sh, false, wdst, limit);
+            } else if (live && p == nsym) {
+                // EOF symbol (codec.rs:108): cum(2^SB) = count - 1, cum(2^SB + 1) = count
+                const uint32_t shifts = encode_symbol<kFix>(S, c - 1, c, c, r, sh, true, wdst, limit);
+                const uint32_t size   = encode_finish(S, shifts, a.code_bits, off0, wdst, limit);
+                a.sizes[blk]  = size;
+                a.status[blk] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
+            }
         }
     }
 }
