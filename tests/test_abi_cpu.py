@@ -73,6 +73,25 @@ def test_geometry():
     assert L.redux_encode_slot_bytes(C.byref(p14), 65536) >= 65536 * 15 // 8
 
 
+def test_small_launches_get_a_pairs_area_and_their_own_kernels():
+    """The kernel choice is host logic (redux_hip.hip: geometry, pick_encode_kernel): launches of at most 2048 slots of
+    u16-node blocks take the small-grid path (redux_coop.hpp) and their workspace holds 8 bytes per input symbol for the
+    (low, high) pairs; larger launches, larger blocks and the other widths do not."""
+    L = _lib.lib()
+    BS = 65536
+    for w in ((8, 30, 32), (8, 14, 16), (8, 20, 24)):
+        p = _lib.Params(*w)
+        small, big = L.redux_encode_workspace_bytes(C.byref(p), 62 * BS, BS), L.redux_encode_workspace_bytes(C.byref(p), 4096 * BS, BS)
+        assert small >= 64 * BS * 8 and big < 4096 * BS * 3      # pairs for whole groups of 64 slots / slots only
+        assert b"k_coop_model" in L.redux_encode_kernel_name(C.byref(p), None, 62 * BS, BS)
+        assert b"k_coop_model" in L.redux_encode_kernel_name(C.byref(p), None, 2048 * BS, BS)
+        assert b"k_encode_pair" in L.redux_encode_kernel_name(C.byref(p), None, 2049 * BS, BS)
+    p = _lib.Params(8, 30, 32)
+    assert b"k_coop" not in L.redux_encode_kernel_name(C.byref(p), None, 10 * 512, 512)          # blocks below 1 KiB
+    assert b"k_coop" not in L.redux_encode_kernel_name(C.byref(p), None, 4 << 20, 1 << 20)        # u32 nodes
+    assert b"k_coop" not in L.redux_encode_kernel_name(C.byref(_lib.Params(12, 20, 32)), None, 62 * BS, BS)
+
+
 def test_worst_case_slot_bound_holds_on_cpu_oracle():
     # adversarial input for a frozen model: saturate one symbol, then send only rare ones
     data = bytes([0]) * 16200 + bytes(range(1, 256)) * 193
