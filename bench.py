@@ -329,7 +329,7 @@ def main():
         import io
         one = host[: 1 << 20].tobytes()
         sink = io.BytesIO()
-        rx.compress(io.BytesIO(one[:4096]), io.BytesIO(), rx.AdaptiveTreeModel.new(rx.Parameters.new(*PARAMS)))
+        rx.compress(io.BytesIO(one), io.BytesIO(), rx.AdaptiveTreeModel.new(rx.Parameters.new(*PARAMS)))  # (sizes the host context)
         t1 = time.perf_counter()
         rx.compress(io.BytesIO(one), sink, rx.AdaptiveTreeModel.new(rx.Parameters.new(*PARAMS)))
         one_lane = len(one) / (time.perf_counter() - t1) / 1e6
@@ -343,8 +343,9 @@ def main():
                       f"of the reference (-O2), {cores} threads, one block per task; single thread: {single:.1f} MB/s; "
                       "sizes of all sampled blocks and bytes of 3 blocks compared with the GPU output",
             "one_lane_drop_in_MBps": round(one_lane, 2),
-            "one_lane_note": "redux_compress (the literal redux::compress drop-in: the first 1 MiB as ONE stream on one GPU lane, "
-                             "PCIe included, bytes equal to the CPU oracle's): for scale against the single-thread figure above",
+            "one_lane_note": "redux_compress (the literal redux::compress drop-in: the first 1 MiB as ONE stream -- its model computed by 64 lanes "
+                             "from prefix counts, its interval chain by one, redux_coop.hpp -- PCIe included, bytes equal to the CPU oracle's): "
+                             "for scale against the single-thread figure above",
         }
     print(json.dumps(line))
     if world > 1:

@@ -30,6 +30,7 @@
 namespace redux {
 
 constexpr uint64_t kCoopMaxBlocks = 2048; // slots, idle table entries included (the pairs take 8 bytes per input byte of workspace: 1 GiB at 2048 x 64 KiB)
+constexpr uint64_t kCoopMaxPairBytes = 3ull << 29; // ... and never more than 1.5 GiB
 constexpr uint32_t kCoopMinBlock  = 1024; // shorter blocks: the per-block set-up (scan, tree build) outweighs the model
 constexpr uint32_t kCoopSlack     = 64;   // symbols of slack behind a group's pairs (the chain wave prefetches unclamped)
 
@@ -44,9 +45,11 @@ __device__ __forceinline__ uint32_t coop_wave_scan(uint32_t v, uint32_t lane)
     return v;
 }
 
+template <bool U16>
 __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
 {
-    __shared__ uint32_t lds[Tree<true>::kDwords];
+    typedef Tree<U16> TreeT;
+    __shared__ uint32_t lds[TreeT::kDwords];
     const uint32_t lane = threadIdx.x;
     const uint64_t ent  = blockIdx.x; // the slot: lane ent & 63 of chain wave ent >> 6
     const uint8_t *src;
@@ -66,9 +69,9 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
     }
     if (len == 0)
         return;
-    for (uint32_t i = lane; i < Tree<true>::kDwords / 4; i += 64)
+    for (uint32_t i = lane; i < TreeT::kDwords / 4; i += 64)
         reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
-    Tree<true> T;
+    TreeT T;
     T.init(lds, lane);
     __syncthreads();
 
@@ -94,16 +97,20 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
                 const uintptr_t ad = C0 + 16 * (uintptr_t)k + i;
                 const uint32_t  s  = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
                 if (k < npieces && ad >= A0 && ad < A1 && (uint32_t)(ad - (uintptr_t)src) < a.nfreeze) // (the model stops counting at the freeze, adaptive_tree.rs:84)
-                    T.add((((s + 1u) & 255u) << Tree<true>::kShift) | T.L, T.inc);
+                    T.add((((s + 1u) & 255u) << TreeT::kShift) | T.L, T.inc);
             }
         }
     }
     __syncthreads();
     // ---- 2. row r: counts of symbol r - 1 in the segments BEFORE this lane's (exclusive scan over the lanes)
     for (uint32_t r = 1; r < 256; r++) {
-        const uint32_t v    = T.node((r << Tree<true>::kShift) | T.L);
+        const uint32_t v    = T.node((r << TreeT::kShift) | T.L);
         const uint32_t incl = coop_wave_scan(v, lane);
-        *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(lds) + ((r << Tree<true>::kShift) | T.L) + 2 * (lane >> 5)) = (uint16_t)(incl - v);
+        char          *cell = reinterpret_cast<char *>(lds) + ((r << TreeT::kShift) | T.L);
+        if (U16)
+            *reinterpret_cast<uint16_t *>(cell + 2 * (lane >> 5)) = (uint16_t)(incl - v);
+        else
+            *reinterpret_cast<uint32_t *>(cell) = incl - v;
     }
     __syncthreads();
     // ---- 3. the Fenwick form in place (node i also covers node i - lowbit(i) + ... : adaptive_tree.rs:43-59): d[i] is
@@ -111,12 +118,12 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
     for (uint32_t i = 1; i < 256; i++) {
         const uint32_t j = i + (i & (0u - i));
         if (j < 256) {
-            const uint32_t v = T.node((i << Tree<true>::kShift) | T.L);
-            T.add((j << Tree<true>::kShift) | T.L, v << T.hsh);
+            const uint32_t v = T.node((i << TreeT::kShift) | T.L);
+            T.add((j << TreeT::kShift) | T.L, v << T.hsh);
         }
     }
     // ---- 4. query + update over the segment (adaptive_tree.rs:63-92), pairs out
-    uint2 *pg = pairs + ((ent >> 6) * ((uint64_t)a.block_size + kCoopSlack)) * 64 + (ent & 63);
+    uint2 *pg = pairs + ((ent >> 6) * ((uint64_t)a.block_size + kCoopSlack)) * a.pair_width + (ent & 63);
     {
         uint4 nx = npieces ? piece(0) : make_uint4(0, 0, 0, 0);
         for (uint32_t k = 0; k < maxpieces; k++) {
@@ -133,8 +140,8 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
                     const uint32_t nup = q < a.nfreeze ? q : a.nfreeze;     // updates before this one
                     uint32_t       lo, hi;
                     // (the update of a block's last symbol is unobservable and skipped: u16 nodes, Tree)
-                    T.template get_frequency<true>(s, nup, q < a.nfreeze && q + 1 != len, lo, hi);
-                    pg[(uint64_t)q * 64] = make_uint2(lo, hi);
+                    T.template get_frequency<true>(s, nup, q < a.nfreeze && (!U16 || q + 1 != len), lo, hi);
+                    pg[(uint64_t)q * a.pair_width] = make_uint2(lo, hi);
                 }
             }
         }
@@ -165,19 +172,21 @@ struct ChainState {
 };
 
 // the narrowing half of encode_symbol_spec: all lanes live, data symbols only
-template <bool CB32>
+template <bool CB32, bool FIXUP>
 __device__ __forceinline__ uint2 chain_step(ChainState &X, uint32_t lo, uint32_t hi, uint32_t c, double rc, uint32_t sh_)
 {
     const uint32_t sh = CB32 ? 0u : sh_;
     const uint32_t R1 = X.r1 >> sh;
     const double   Y  = __builtin_fma((double)R1, rc, rc);
     asm volatile("" : "+v"(hi)); // (the high half of an 8-byte load: keeps ISel from converting it as u64 >> 32, +1 v_add_f64; see coder_chunk)
-    const uint32_t nlow   = X.low + (scale_div<false>(R1, Y, lo, c) << sh);
-    const uint32_t nihigh = 0u - (X.low + (scale_div<false, true>(R1, Y, hi, c) << sh));
+    const uint32_t nlow   = X.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
+    const uint32_t nihigh = 0u - (X.low + (scale_div<FIXUP, true>(R1, Y, hi, c) << sh));
     const uint32_t x      = ~(nlow ^ nihigh);
-    const uint32_t k      = CB32 ? (uint32_t)__builtin_clz(x) : (x ? (uint32_t)__builtin_clz(x) : 32u);
+    // (32-bit codes with count < 2^17: low != high after every symbol, encode_symbol_spec)
+    constexpr bool kNonZero = CB32 && !FIXUP;
+    const uint32_t k      = kNonZero ? (uint32_t)__builtin_clz(x) : (x ? (uint32_t)__builtin_clz(x) : 32u);
     const uint64_t sl     = (uint64_t)nlow << k;
-    const uint32_t ih2    = CB32 ? nihigh << k : (uint32_t)((uint64_t)nihigh << k);
+    const uint32_t ih2    = kNonZero ? nihigh << k : (uint32_t)((uint64_t)nihigh << k);
     const uint32_t low2   = (uint32_t)sl;
     const uint32_t nt     = ((~(low2 & ih2)) << 1) | 1u;
     const uint32_t j      = (uint32_t)__builtin_clz(nt);
@@ -190,15 +199,15 @@ __device__ __forceinline__ uint2 chain_step(ChainState &X, uint32_t lo, uint32_t
 
 // the same for any lane state: act = this lane codes a symbol at this step, eof = it is the EOF symbol (codec.rs:91-99:
 // high unchanged, encode_symbol); returns the message, shifts = k + j
-template <bool CB32>
+template <bool CB32, bool FIXUP>
 __device__ __forceinline__ uint2 chain_step_any(ChainState &X, uint32_t lo, uint32_t hi, uint32_t c, double rc, uint32_t sh,
                                                 bool act, bool eof, uint32_t &shifts)
 {
     const uint32_t ihm = X.ih & 0x7FFFFFFFu;
     const uint32_t R1  = (~(ihm + X.low)) >> sh;
     const double   Y   = __builtin_fma((double)R1, rc, rc);
-    const uint32_t nlow   = X.low + (scale_div<false>(R1, Y, lo, c) << sh);
-    const uint32_t nihigh = eof ? ihm : ~(X.low + (scale_div<false, true>(R1, Y, eof ? 1u : hi, c) << sh) - 1u);
+    const uint32_t nlow   = X.low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
+    const uint32_t nihigh = eof ? ihm : ~(X.low + (scale_div<FIXUP, true>(R1, Y, eof ? 1u : hi, c) << sh) - 1u);
     const uint32_t x      = ~(nlow ^ nihigh);
     const uint32_t k      = x ? (uint32_t)__builtin_clz(x) : 32u;
     const uint64_t sl     = (uint64_t)nlow << k;
@@ -256,7 +265,7 @@ __device__ __forceinline__ void emit_careful(EncState &S, uint32_t topk, uint32_
     }
 }
 
-template <bool CB32>
+template <bool CB32, bool FIXUP>
 __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pairs)
 {
     __shared__ uint2 ring[kCoopRing / 8];
@@ -288,13 +297,14 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
         // a lane without a block runs the lock-step part on a copy of the wave's first live block (valid pairs: its own
         // column of the workspace was never written) and sends empty messages after it
         const uint32_t col  = live ? lane : (uint32_t)__builtin_ctzll(lives);
-        const uint64_t gcol = (uint64_t)blockIdx.x * (a.block_size + kCoopSlack) * 64;
+        const uint32_t pw   = a.pair_width; // lanes per row of the pairs: 64, or the number of blocks of a launch of fewer
+        const uint64_t gcol = (uint64_t)blockIdx.x * ((uint64_t)a.block_size + kCoopSlack) * pw;
         const uint2   *pg   = pairs + gcol + col;
         auto load16 = [&](uint2 (&d)[16], uint32_t p) { // (up to 47 symbols past the last chunk: inside the slack)
-            const uint2 *q = pg + (uint64_t)p * 64;
+            const uint2 *q = pg + (uint64_t)p * pw;
 #pragma unroll
             for (int i = 0; i < 16; i++)
-                d[i] = q[i * 64];
+                d[i] = q[(uint32_t)i * pw];
         };
         ChainState X;
         X.low = 0; X.ih = 0; X.r1 = 0xFFFFFFFFu;
@@ -328,8 +338,8 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                     }
 #pragma unroll
                     for (int i = 0; i < 16; i += 2) {
-                        const uint2 m0 = chain_step<CB32>(X, cur[i].x, cur[i].y, 257u + nup[i], r[i], sh);
-                        const uint2 m1 = chain_step<CB32>(X, cur[i + 1].x, cur[i + 1].y, 257u + nup[i + 1], r[i + 1], sh);
+                        const uint2 m0 = chain_step<CB32, FIXUP>(X, cur[i].x, cur[i].y, 257u + nup[i], r[i], sh);
+                        const uint2 m1 = chain_step<CB32, FIXUP>(X, cur[i + 1].x, cur[i + 1].y, 257u + nup[i + 1], r[i + 1], sh);
                         *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m0.x, m0.y, m1.x, m1.y);
                     }
                 } else { // from the shortest block's last chunk on: what a lane does with a symbol is its own matter
@@ -343,7 +353,7 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                             const uint32_t qm  = q < maxlen ? q : maxlen;      // (the reciprocal table ends at min(maxlen, nfreeze) + slack)
                             const uint32_t qc  = qm < nfreeze ? qm : nfreeze; // updates before symbol q
                             uint32_t       shifts;
-                            m[e] = chain_step_any<CB32>(X, eof ? 256u + qc : cur[i + e].x, cur[i + e].y, 257u + qc, rc[qc], sh, act, eof, shifts);
+                            m[e] = chain_step_any<CB32, FIXUP>(X, eof ? 256u + qc : cur[i + e].x, cur[i + e].y, 257u + qc, rc[qc], sh, act, eof, shifts);
                             if (act && eof)
                                 fin[lane] = make_uint2(X.low, shifts);
                         }

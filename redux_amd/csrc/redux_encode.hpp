@@ -52,6 +52,7 @@ struct EncArgs {
     // codes: its first byte is in + offset (offset < 2^32), it is `length` <= block_size bytes long, and its size and
     // status belong to entry `index` of the output tables.
     const redux_block *table;
+    uint32_t       pair_width; // small-grid kernels (redux_coop.hpp): lanes per row of the (low, high) pairs in the workspace
 };
 
 // A table entry with this index is an idle lane: redux_block_table_v pads the table with them so that blocks of very

@@ -117,6 +117,7 @@ struct Geometry {
     bool     gen;        // ... except 4- and 12-bit symbols with code_bits <= 32: lock-step kernels of redux_gen.hpp
     uint64_t tree_bytes; // any / gen (12-bit symbols): per-block tree in the workspace
     bool     coop;       // small grid: k_coop_model + k_coop_chain (redux_coop.hpp), (low, high) pairs in the workspace
+    uint32_t pair_width; // ... in rows of this many lanes
     // workspace layout (encode)
     uint64_t off_rc, off_sizes, off_mode, off_slots, off_trees, off_pairs, total;
 };
@@ -229,10 +230,14 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode
     g.off_trees = align_up(g.off_slots + ((g.nblocks + 63) / 64 * 64 + 1) * g.slot_bytes + (g.nblocks + 63) / 64 * 128, 256);
     g.off_pairs = align_up(g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes, 256); // gen: whole waves
-    // a grid that leaves most SIMDs idle: the model by 64 lanes per block, the chain by one (u16 nodes)
-    g.coop = !static_model && !g.any && !g.gen && g.u16 && !g.fixup && g.nblocks <= kCoopMaxBlocks && block_size >= kCoopMinBlock &&
-             64ull * g.slot_bytes < (1ull << 32);
-    g.total = g.off_pairs + (g.coop ? (g.nblocks + 63) / 64 * 64 * ((uint64_t)block_size + kCoopSlack) * 8 : 0);
+    // a grid that leaves most SIMDs idle: the model by 64 lanes per block, the chain by one.  One block of any length --
+    // redux_compress, the literal redux::compress -- is such a grid.  The pairs are rows of pair_width lanes (64, or the
+    // number of blocks when there are fewer), block_size + slack rows per group of 64 blocks.
+    g.pair_width = g.nblocks < 64 ? (uint32_t)g.nblocks : 64u;
+    const uint64_t pair_bytes = (g.nblocks + 63) / 64 * g.pair_width * ((uint64_t)block_size + kCoopSlack) * 8;
+    g.coop = !static_model && !g.any && !g.gen && g.nblocks <= kCoopMaxBlocks && block_size >= kCoopMinBlock &&
+             64ull * g.slot_bytes < (1ull << 32) && pair_bytes <= kCoopMaxPairBytes;
+    g.total = g.off_pairs + (g.coop ? pair_bytes : 0);
     return g;
 }
 
@@ -341,8 +346,8 @@ const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, ui
     const Geometry g = geometry(p, in_len, block_size);
     const bool aligned16 = (((uintptr_t)d_in) & 15) == 0 && (block_size & 15) == 0;
     switch (pick_encode_kernel(g, p, aligned16, block_size)) {
-    case EncKernel::CoopCb32: return "k_coop_model + k_coop_chain<true> (small grid: model by 64 lanes per block, chain by one, code_bits 32)";
-    case EncKernel::Coop: return "k_coop_model + k_coop_chain<false> (small grid: model by 64 lanes per block, chain by one)";
+    case EncKernel::CoopCb32: return "k_coop_model + k_coop_chain<true> (small grid: model by 64 lanes per block, chain wave + bit-writer wave, code_bits 32)";
+    case EncKernel::Coop: return "k_coop_model + k_coop_chain<false> (small grid: model by 64 lanes per block, chain wave + bit-writer wave)";
     case EncKernel::PairCb32: return "k_encode_pair<false, true> (u16 tree, model wave + coder wave, code_bits 32)";
     case EncKernel::Pair: return "k_encode_pair<false, false> (u16 tree, model wave + coder wave)";
     case EncKernel::SingleU16: return "k_encode<true, false> (u16 tree, one wave per 64 blocks)";
@@ -497,6 +502,7 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
     a.aligned16  = ((((uintptr_t)d_in) & 15) == 0 && (d_table ? tbl_aligned16 : (block_size & 15) == 0)) ? 1 : 0;
     a.claims     = (uint32_t *)(ws + g.off_mode + 256);
     a.table      = d_table;
+    a.pair_width = g.pair_width;
     // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset;
     // otherwise (giant blocks, whole-stream mode) one block per wave.
     a.lanes = encode_lanes(g, block_size);
@@ -509,12 +515,20 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
     switch (which) {
     case EncKernel::CoopCb32:
     case EncKernel::Coop: {
-        uint2 *pairs = (uint2 *)(ws + g.off_pairs);
-        k_coop_model<<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
-        if (which == EncKernel::CoopCb32)
-            k_coop_chain<true><<<grid, 128, 0, s>>>(a, pairs);
+        uint2         *pairs = (uint2 *)(ws + g.off_pairs);
+        const uint32_t cgrid = (uint32_t)((g.nblocks + 63) / 64);
+        const bool     cb32  = which == EncKernel::CoopCb32;
+        if (g.u16)
+            k_coop_model<true><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
         else
-            k_coop_chain<false><<<grid, 128, 0, s>>>(a, pairs);
+            k_coop_model<false><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
+        if (g.fixup) {
+            if (cb32) k_coop_chain<true, true><<<cgrid, 128, 0, s>>>(a, pairs);
+            else      k_coop_chain<false, true><<<cgrid, 128, 0, s>>>(a, pairs);
+        } else {
+            if (cb32) k_coop_chain<true, false><<<cgrid, 128, 0, s>>>(a, pairs);
+            else      k_coop_chain<false, false><<<cgrid, 128, 0, s>>>(a, pairs);
+        }
         break;
     }
     case EncKernel::PairCb32: k_encode_pair<false, true><<<grid, 128, 0, s>>>(a); break;
@@ -572,7 +586,7 @@ static int compact_with(const Geometry &g, void *d_out, uint64_t out_cap, void *
     ca.cap_rows   = (uint32_t)(g.slot_bytes / 4);
     ca.table      = d_table;
     k_compact<<<(uint32_t)g.nblocks, 256, 0, s>>>(ca);
-    if (!g.any && g.u16) {
+    if (!g.any && !g.gen && (g.u16 || g.coop)) { // (every launch that may have left row-major group areas: the kernel reads the mode word)
         const uint32_t tiles = (ca.cap_rows + kTileRows - 1) / kTileRows + 1;
         const uint32_t groups = (uint32_t)((g.nblocks + 63) / 64);
         k_compact_rows<<<(groups + 7) / 8 * 8 * tiles, 256, 0, s>>>(ca); // (whole sets of 8 groups: k_compact_rows' XCD-aware mapping)

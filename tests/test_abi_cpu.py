@@ -88,7 +88,9 @@ def test_small_launches_get_a_pairs_area_and_their_own_kernels():
         assert b"k_encode_pair" in L.redux_encode_kernel_name(C.byref(p), None, 2049 * BS, BS)
     p = _lib.Params(8, 30, 32)
     assert b"k_coop" not in L.redux_encode_kernel_name(C.byref(p), None, 10 * 512, 512)          # blocks below 1 KiB
-    assert b"k_coop" not in L.redux_encode_kernel_name(C.byref(p), None, 4 << 20, 1 << 20)        # u32 nodes
+    assert b"k_coop" in L.redux_encode_kernel_name(C.byref(p), None, 1 << 20, 1 << 20)           # ONE block of any length (redux_compress): u32 nodes
+    assert L.redux_encode_workspace_bytes(C.byref(p), 1 << 20, 1 << 20) < (1 << 20) * 90         # ... its pairs in rows of one lane, not 64
+    assert b"k_coop" not in L.redux_encode_kernel_name(C.byref(p), None, 2048 << 20, 1 << 20)    # pairs beyond 1.5 GiB
     assert b"k_coop" not in L.redux_encode_kernel_name(C.byref(_lib.Params(12, 20, 32)), None, 62 * BS, BS)
 
 

@@ -917,8 +917,10 @@ def test_kernel_names_follow_the_dispatch(rx):
     assert enc((8, 30, 32), 0, 1 << 30, 65536).startswith("k_encode_pair<false, true>")
     assert enc((8, 14, 16), 0, 1 << 30, 65536).startswith("k_encode_pair<false, false>")
     assert enc((8, 30, 32), 4, 1 << 30, 65536).startswith("k_encode<true, false>")     # unaligned input
-    assert enc((8, 30, 32), 0, 1 << 30, 1 << 20).startswith("k_encode<false, true>")    # u32 tree
-    assert enc((12, 14, 16), 0, 1 << 20, 65536).startswith("k_encode_gen<12>")
+    assert enc((8, 30, 32), 0, 1 << 32, 1 << 20).startswith("k_encode<false, true>")    # u32 tree
+    assert enc((8, 30, 32), 0, 1 << 20, 1 << 20).startswith("k_coop_model")             # one block of any length: redux_compress
+    assert enc((8, 30, 32), 0, 62 << 16, 65536).startswith("k_coop_model")              # a small launch
+    assert enc((12, 14, 16), 0, 1 << 20, 65536).startswith("k_encode_gen_pair<12>")
     assert enc((4, 10, 16), 0, 1 << 20, 65536).startswith("k_encode_gen<4>")
     assert enc((12, 20, 44), 0, 1 << 20, 65536).startswith("k_encode_any")              # code_bits > 32
     assert enc((5, 10, 16), 0, 1 << 20, 65536).startswith("k_encode_any")
