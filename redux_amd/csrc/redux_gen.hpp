@@ -238,18 +238,18 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
 }
 
 // 12-bit symbols: the LDS holds 16 trees per CU, so a CU runs ONE workgroup and three of its SIMDs would idle.  The
-// same kernel as three waves on three SIMDs: waves 0 and 1 are the model, each for half of the tree's levels (symbol
-// load a step ahead, six of the twelve fetch-adds -- they are independent -- and their share of the two masked sums ->
-// a partial (low, high) into an LDS ring of its own), wave 2 the coder (adds the shares; interval narrowing,
-// renormalisation, bit output, EOF tail); a half of eight symbols is handed over per s_barrier, as in k_encode_pair.  A
-// step costs the longest of the three instead of their sum (8.6 -> 14 GB/s with one model wave, ... with two).  All
-// waves derive the same schedule from wave-uniform values.
+// same kernel as four waves on four SIMDs: waves 0-2 are the model, each for four of the tree's twelve levels (symbol
+// load a step ahead, its fetch-adds -- the twelve are independent -- and its share of the two masked sums -> a partial
+// (low, high) into an LDS ring of its own), wave 3 the coder (adds the shares; interval narrowing, renormalisation, bit
+// output, EOF tail); a half of eight symbols is handed over per s_barrier, as in k_encode_pair.  A step costs the
+// longest of the four instead of their sum: 8.6 GB/s as one wave, 14.0 with one model wave, 20.5 with two, 23.3 with
+// three (the coder wave is the longest then).  All waves derive the same schedule from wave-uniform values.
 template <int SB>
-__global__ void __launch_bounds__(192) k_encode_gen_pair(GenEncArgs a)
+__global__ void __launch_bounds__(256) k_encode_gen_pair(GenEncArgs a)
 {
     typedef GenTree<SB> Tree;
-    constexpr uint32_t kHalf = 8, kModelWaves = 2;
-    constexpr int      kSplit = SB / 2;
+    constexpr uint32_t kHalf = 8, kModelWaves = 3;
+    constexpr int      kSplit1 = SB / 3, kSplit2 = 2 * SB / 3;
     __shared__ uint32_t lds[Tree::kDwords];
     __shared__ uint2    ring[kModelWaves][2 * kHalf * 64];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(192) k_encode_gen_pair(GenEncArgs a)
     const uint64_t blk0 = (uint64_t)blockIdx.x * Tree::kBlocks;
     const uint64_t blk  = blk0 + lane;
     const bool     live = lane < Tree::kBlocks && blk < a.nblocks;
-    for (uint32_t i = threadIdx.x; i < Tree::kDwords / 4; i += 192)
+    for (uint32_t i = threadIdx.x; i < Tree::kDwords / 4; i += 256)
         reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
@@ -296,9 +296,11 @@ __global__ void __launch_bounds__(192) k_encode_gen_pair(GenEncArgs a)
                 uint32_t lo = 0, hi = 0;
                 if (live && p < nsym) {
                     if (wave == 0)
-                        T.template get_frequency_part<0, kSplit>(sym, nup, p < nfreeze, lo, hi);
+                        T.template get_frequency_part<0, kSplit1>(sym, nup, p < nfreeze, lo, hi);
+                    else if (wave == 1)
+                        T.template get_frequency_part<kSplit1, kSplit2>(sym, nup, p < nfreeze, lo, hi);
                     else
-                        T.template get_frequency_part<kSplit, SB>(sym, nup, p < nfreeze, lo, hi);
+                        T.template get_frequency_part<kSplit2, SB>(sym, nup, p < nfreeze, lo, hi);
                 }
                 my[((t & 1u) * kHalf + i) * 64 + lane] = make_uint2(lo, hi);
             }
@@ -319,8 +321,9 @@ __global__ void __launch_bounds__(192) k_encode_gen_pair(GenEncArgs a)
         uint2 lh[kHalf];
 #pragma unroll
         for (uint32_t i = 0; i < kHalf; i++) {
-            const uint2 p0 = ring[0][((t & 1u) * kHalf + i) * 64 + lane], p1 = ring[1][((t & 1u) * kHalf + i) * 64 + lane];
-            lh[i] = make_uint2(p0.x + p1.x, p0.y + p1.y);
+            const uint32_t at = ((t & 1u) * kHalf + i) * 64 + lane;
+            const uint2    p0 = ring[0][at], p1 = ring[1][at], p2 = ring[2][at];
+            lh[i] = make_uint2(p0.x + p1.x + p2.x, p0.y + p1.y + p2.y);
         }
         // (count <= 2^SB + 1 + 65535 < 2^17 for the u16 trees: the quotients need no fix-up, scale_div)
         constexpr bool kFix = (1u << SB) + 1u + Tree::kMaxSymbols >= (1u << 17);

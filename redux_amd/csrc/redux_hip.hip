@@ -354,7 +354,7 @@ const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, ui
     case EncKernel::SingleU16Fixup: return "k_encode<true, true> (u16 tree, one wave per 64 blocks, quotient fix-up)";
     case EncKernel::SingleU32: return "k_encode<false, true> (u32 tree)";
     case EncKernel::Gen4: return "k_encode_gen<4> (4-bit symbols, lock-step, u32 tree in LDS)";
-    case EncKernel::Gen12: return "k_encode_gen_pair<12> (12-bit symbols, lock-step, u16 tree in LDS, 16 blocks per workgroup: two model waves + coder wave)";
+    case EncKernel::Gen12: return "k_encode_gen_pair<12> (12-bit symbols, lock-step, u16 tree in LDS, 16 blocks per workgroup: three model waves + coder wave)";
     case EncKernel::Any: return "k_encode_any (general parameters, one lane per block)";
     }
     return "";
@@ -461,7 +461,7 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
         if (p->symbol_bits == 4)
             k_encode_gen<4><<<(uint32_t)((g.nblocks + 63) / 64), 64, 0, s>>>(ga);
         else
-            k_encode_gen_pair<12><<<(uint32_t)((g.nblocks + GenTree<12>::kBlocks - 1) / GenTree<12>::kBlocks), 192, 0, s>>>(ga);
+            k_encode_gen_pair<12><<<(uint32_t)((g.nblocks + GenTree<12>::kBlocks - 1) / GenTree<12>::kBlocks), 256, 0, s>>>(ga);
         HIP_TRY(hipGetLastError());
         return REDUX_OK;
     }
