@@ -156,29 +156,40 @@ def decode_file_sharded(dense, offsets, block_size, decode_local, device, group=
 
 
 # ---- production local coders (HBM-resident, the HIP path) ------------------------------------
+# A rank codes many ranges of similar size: the coder objects (workspace, bound-sized output, offsets, status) are kept
+# per (block size, device) and only replaced by a larger one; one summary read-back per call is the only synchronisation,
+# and the results are views of the coder's buffers handed to the collective that follows (valid until the next call).
 def hip_encode_local(params):
     from . import api
+    cache = {}
 
     def f(t, block_size):
-        enc = api.DeviceEncoder(params, block_size, max(t.numel(), 1), device=str(t.device))
+        key = (int(block_size), str(t.device))
+        enc = cache.get(key)
+        if enc is None or enc.max_in_len < t.numel():
+            enc = cache[key] = api.DeviceEncoder(params, block_size, max(t.numel(), 1), device=str(t.device))
         out, offs, status, summary = enc.encode(t)
-        torch.cuda.synchronize(t.device)
-        st = summary.tolist()
+        nb = offs.numel() - 1
+        st = torch.cat([summary.to(torch.int64), offs[nb: nb + 1]]).tolist()  # (one read-back: summary + total size)
         if st[0] != 0:
             api._raise(st[0])
-        return out[: int(offs[-1].item())].clone(), offs.clone()
+        return out[: st[2]], offs
     return f
 
 
 def hip_decode_local(params):
     from . import api
+    cache = {}
 
     def f(dense, offs, block_size):
-        dec = api.DeviceDecoder(params, block_size, offs.numel() - 1, device=str(dense.device))
+        nb = offs.numel() - 1
+        key = (int(block_size), str(dense.device))
+        dec = cache.get(key)
+        if dec is None or dec.max_blocks < nb:
+            dec = cache[key] = api.DeviceDecoder(params, block_size, nb, device=str(dense.device))
         out, sizes, status, summary = dec.decode(dense.contiguous(), offs.contiguous())
-        torch.cuda.synchronize(dense.device)
         st = summary.tolist()
         if st[0] != 0:
             api._raise(st[0])
-        return out.clone(), sizes.to(torch.int64)
+        return out, sizes.to(torch.int64)
     return f
