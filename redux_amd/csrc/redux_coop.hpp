@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace redux {
 
@@ -302,12 +303,23 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
         const uint2   *pg   = pairs + gcol + col;
         auto load16 = [&](uint2 (&d)[16], uint32_t p) { // (up to 47 symbols past the last chunk: inside the slack)
             const uint2 *q = pg + (uint64_t)p * pw;
+            if (__builtin_expect(pw == 64, 1)) { // (wave-uniform) whole groups: the row offsets are immediates of the sixteen loads
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                d[i] = q[(uint32_t)i * pw];
+                for (int i = 0; i < 16; i++)
+                    d[i] = q[i * 64];
+            } else if (pw == 1) { // one block of any length (redux_compress): its pairs are contiguous
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    d[i] = q[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    d[i] = q[(uint32_t)i * pw];
+            }
         };
         ChainState X;
         X.low = 0; X.ih = 0; X.r1 = 0xFFFFFFFFu;
+        const double rcF = rc[maxlen < nfreeze ? maxlen : nfreeze]; // (the table ends at min(longest block, freeze point) + slack)
         // Chunks of 16 symbols; the pairs of chunk c + 2 are requested when chunk c starts (three register buffers whose
         // roles rotate: the loop is unrolled by three so that no copy -- which would wait for the newest loads -- moves
         // them).  Every chunk is loaded without a lane predicate (a short block's column is garbage behind its end, the
@@ -316,53 +328,75 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
         uint2 buf[3][16];
         load16(buf[0], 0);
         load16(buf[1], 16);
-        for (uint32_t c0 = 0; c0 < nchunks; c0 += 3) {
+        // One chunk.  U: which of the three buffers holds it (a constant of the unrolled code).  HOT: the chunk is known to
+        // lie below the shortest block's end AND below the freeze point -- sixteen lock-step symbols of an adapting model,
+        // their counts an induction variable and their reciprocals two wide scalar loads, no branch; otherwise everything is
+        // decided here: behind the freeze point the count and reciprocal are scalar selects per symbol (a lone wave pays an
+        // issue slot for scalar instructions too, hence the separate hot copy), and from the shortest block's last chunk on
+        // what a lane does with a symbol is its own matter.
+        auto chunk = [&](auto u_tag, auto hot_tag, const uint32_t c) {
+            constexpr int  U   = decltype(u_tag)::value;
+            constexpr bool HOT = decltype(hot_tag)::value;
+            const uint32_t p = 16 * c, ro = (c & 3u) * 16u;
+            uint2 (&cur)[16] = buf[U];
+            load16(buf[(U + 2) % 3], p + 32);
+            // one wait for the whole chunk: the 32 loads issued since (this chunk's and the previous one's) may stay
+            // in flight (vmcnt(32); the lgkmcnt / expcnt fields all ones = no wait)
+            __builtin_amdgcn_s_waitcnt(0x8F70);
+            if (HOT || p + 16 <= main_end) {
+                const uint32_t pb = HOT ? p : (p < nfreeze ? p : nfreeze); // (sixteen consecutive entries: inside the table's slack)
+                double         r[16];
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
-                const uint32_t c = c0 + u;
-                if (c >= nchunks)
-                    break;
-                const uint32_t p = 16 * c, ro = (c & 3u) * 16u;
-                uint2 (&cur)[16] = buf[u];
-                load16(buf[(u + 2) % 3], p + 32);
-                // one wait for the whole chunk: the 32 loads issued since (this chunk's and the previous one's) may stay
-                // in flight (vmcnt(32); the lgkmcnt / expcnt fields all ones = no wait)
-                __builtin_amdgcn_s_waitcnt(0x8F70);
-                if (p + 16 <= main_end) {
-                    double   r[16];
-                    uint32_t nup[16]; // updates before symbol p + i (wave-uniform: scalar registers)
+                for (int i = 0; i < 16; i++)
+                    r[i] = rc[pb + i];
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        nup[i] = p + i < nfreeze ? p + i : nfreeze;
-                        r[i]   = rc[nup[i]];
+                for (int i = 0; i < 16; i += 2) {
+                    uint2 m[2];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const bool     upd = HOT || p + i + e < nfreeze;
+                        const uint32_t n   = upd ? p + i + e : nfreeze;
+                        m[e] = chain_step<CB32, FIXUP>(X, cur[i + e].x, cur[i + e].y, 257u + n, upd ? r[i + e] : rcF, sh);
                     }
-#pragma unroll
-                    for (int i = 0; i < 16; i += 2) {
-                        const uint2 m0 = chain_step<CB32, FIXUP>(X, cur[i].x, cur[i].y, 257u + nup[i], r[i], sh);
-                        const uint2 m1 = chain_step<CB32, FIXUP>(X, cur[i + 1].x, cur[i + 1].y, 257u + nup[i + 1], r[i + 1], sh);
-                        *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m0.x, m0.y, m1.x, m1.y);
-                    }
-                } else { // from the shortest block's last chunk on: what a lane does with a symbol is its own matter
-#pragma unroll
-                    for (int i = 0; i < 16; i += 2) {
-                        uint2 m[2];
-#pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            const uint32_t q   = p + i + e;
-                            const bool     act = live && q <= len, eof = q == len;
-                            const uint32_t qm  = q < maxlen ? q : maxlen;      // (the reciprocal table ends at min(maxlen, nfreeze) + slack)
-                            const uint32_t qc  = qm < nfreeze ? qm : nfreeze; // updates before symbol q
-                            uint32_t       shifts;
-                            m[e] = chain_step_any<CB32, FIXUP>(X, eof ? 256u + qc : cur[i + e].x, cur[i + e].y, 257u + qc, rc[qc], sh, act, eof, shifts);
-                            if (act && eof)
-                                fin[lane] = make_uint2(X.low, shifts);
-                        }
-                        *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m[0].x, m[0].y, m[1].x, m[1].y);
-                    }
+                    *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m[0].x, m[0].y, m[1].x, m[1].y);
                 }
-                if (c & 1u)
-                    pair_barrier();
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    uint2 m[2];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const uint32_t q   = p + i + e;
+                        const bool     act = live && q <= len, eof = q == len;
+                        const uint32_t qm  = q < maxlen ? q : maxlen;      // (the reciprocal table ends at min(maxlen, nfreeze) + slack)
+                        const uint32_t qc  = qm < nfreeze ? qm : nfreeze; // updates before symbol q
+                        uint32_t       shifts;
+                        m[e] = chain_step_any<CB32, FIXUP>(X, eof ? 256u + qc : cur[i + e].x, cur[i + e].y, 257u + qc, rc[qc], sh, act, eof, shifts);
+                        if (act && eof)
+                            fin[lane] = make_uint2(X.low, shifts);
+                    }
+                    *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m[0].x, m[0].y, m[1].x, m[1].y);
+                }
             }
+            if (c & 1u)
+                pair_barrier();
+        };
+        typedef std::integral_constant<int, 0> U0;
+        typedef std::integral_constant<int, 1> U1;
+        typedef std::integral_constant<int, 2> U2;
+        const uint32_t hot_end = main_end < nfreeze ? main_end : nfreeze; // symbols that are lock-step AND adaptive
+        uint32_t       c0      = 0;
+        for (; 16 * (c0 + 3) <= hot_end; c0 += 3) { // whole triples of hot chunks: one straight run of code
+            chunk(U0(), std::true_type(), c0);
+            chunk(U1(), std::true_type(), c0 + 1);
+            chunk(U2(), std::true_type(), c0 + 2);
+        }
+        for (; c0 < nchunks; c0 += 3) {
+            chunk(U0(), std::false_type(), c0);
+            if (c0 + 1 < nchunks)
+                chunk(U1(), std::false_type(), c0 + 1);
+            if (c0 + 2 < nchunks)
+                chunk(U2(), std::false_type(), c0 + 2);
         }
         return;
     }

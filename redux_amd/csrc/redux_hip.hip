@@ -232,8 +232,8 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.off_pairs = align_up(g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes, 256); // gen: whole waves
     // a grid that leaves most SIMDs idle: the model by 64 lanes per block, the chain by one.  One block of any length --
     // redux_compress, the literal redux::compress -- is such a grid.  The pairs are rows of pair_width lanes (64, or the
-    // number of blocks when there are fewer), block_size + slack rows per group of 64 blocks.
-    g.pair_width = g.nblocks < 64 ? (uint32_t)g.nblocks : 64u;
+    // number of blocks when there are fewer and they are large), block_size + slack rows per group of 64 blocks.
+    g.pair_width = (g.nblocks < 64 && !g.u16) ? (uint32_t)g.nblocks : 64u; // (large blocks only: a constant row stride is faster to address)
     const uint64_t pair_bytes = (g.nblocks + 63) / 64 * g.pair_width * ((uint64_t)block_size + kCoopSlack) * 8;
     g.coop = !static_model && !g.any && !g.gen && g.nblocks <= kCoopMaxBlocks && block_size >= kCoopMinBlock &&
              64ull * g.slot_bytes < (1ull << 32) && pair_bytes <= kCoopMaxPairBytes;
