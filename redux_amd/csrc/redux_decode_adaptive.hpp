@@ -26,7 +26,13 @@
 //   * sixteen steps per loop iteration: the decoded bytes of an iteration collect in four registers with static
 //     roles and leave as one 16-byte store per lane; the stream comes through a ring in LDS fed by one 16-byte load
 //     per lane and group of four steps, consumed a group later (a lock-step wave waits for the slowest of 64 lanes
-//     on every vector-memory wait, so nothing in a step may depend on a load younger than that).
+//     on every vector-memory wait, so nothing in a step may depend on a load younger than that).  The chunk load
+//     itself is UNCONDITIONAL (a chunk that crosses its stream's end is patched up in a rarely entered block, by
+//     selects): inside an exec-masked region next to such a block, the join made the compiler wait for the load it
+//     had just issued, once per group -- 24.6 against 20.8 ms.
+//   * the sixteen-step loop exists twice: while every step updates the model, and -- for models that freeze inside a
+//     block (frequency bits <= 16) -- with count, reciprocal and addends selected per step, so that a block past its
+//     freeze point stays in lock-step form.
 //
 // Included by redux_hip.hip (one translation unit).
 #pragma once

@@ -1292,3 +1292,24 @@ def test_small_grid_kernels_on_a_hand_made_table(rx):
         for b, d in enumerate(datas):
             want, _ = ox.compress(d, w)
             assert out[int(offs[b]): int(offs[b + 1])].tobytes() == want, (w, b, len(d))
+
+
+def test_small_grid_kernels_on_large_blocks(rx):
+    """Blocks past 64 KiB on the small-launch kernels: u32 tree nodes in k_coop_model, the quotient fix-up in the chain wave
+    (the count passes 2^17 inside a 300,000-byte block), pairs in rows as wide as the launch, a ragged last block; and ONE
+    block of 1.5 MB: what redux_compress runs.  Streams equal the oracle's, the decode returns the bytes."""
+    import ctypes as C
+    from redux_amd import _lib
+    rng = np.random.default_rng(77)
+    text = open(os.path.join(GOLDEN, "corpora", "large", "world192.txt"), "rb").read()
+    for w, bs, n in (((8, 30, 32), 300_000, 1_333_333), ((8, 22, 24), 300_000, 700_001), ((8, 30, 32), 1_500_000, 1_500_000)):
+        cp = _lib.Params(*w)
+        assert b"k_coop_model" in _lib.lib().redux_encode_kernel_name(C.byref(cp), None, n, bs)
+        data = text[: n // 2] + bytes((rng.integers(0, 256, n - n // 2, dtype=np.uint8) >> 2).tolist())
+        out, offs, st = rx.compress_blocks(data, bs, w)
+        assert not st.any()
+        for b in range(len(offs) - 1):
+            want, _ = ox.compress(data[b * bs:(b + 1) * bs], w)
+            assert out[int(offs[b]): int(offs[b + 1])].tobytes() == want, (w, bs, b)
+        dec, sizes, dst = rx.decompress_blocks(out, offs, bs, w)
+        assert not dst.any() and b"".join(dec[b * bs: b * bs + int(sizes[b])].tobytes() for b in range(len(sizes))) == data
