@@ -3,7 +3,7 @@
 // One translation unit; the kernels (all hand-written for CDNA4, wave64) live in
 //   redux_coder.hpp    device building blocks: LDS tree, interval narrowing, bit output
 //   redux_encode.hpp   k_fill_rc, k_encode, k_encode_pair (default encoder)
-//   redux_decode.hpp   k_decode, k_decode_lock (default decoder)
+//   redux_decode.hpp   k_decode, k_decode_lock (default decoder); redux_decode_wave.hpp: k_decode_wave (small launches, whole streams)
 //   redux_pack.hpp     k_scan_sizes, k_compact: slots -> dense stream + offsets
 //   redux_coop.hpp     k_coop_model, k_coop_chain: small grids, a block's model computed by 64 lanes
 //   redux_any.hpp      general Parameters (symbol_bits <= 16, code_bits <= 63), one lane per block
@@ -20,6 +20,7 @@
 #include "redux_encode.hpp"
 #include "redux_decode.hpp"
 #include "redux_decode_adaptive.hpp"
+#include "redux_decode_wave.hpp"
 #include "redux_pack.hpp"
 #include "redux_coop.hpp"
 #include "redux_synth.hpp"
@@ -270,7 +271,7 @@ static uint32_t cu_count()
 // ---- which kernel a call runs: ONE decision, used by the launch code and reported by
 // redux_encode_kernel_name / redux_decode_kernel_name (bench.py's roofline.kernel) ------------
 enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Gen4, Gen12, Any, CoopCb32, Coop };
-enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Gen4, Gen12, Any };
+enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Gen4, Gen12, Any, Wave, WaveFixup };
 
 // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset; otherwise
 // (giant blocks, whole-stream mode) one block per wave.
@@ -306,12 +307,23 @@ static EncKernel pick_encode_kernel(const Geometry &g, const redux_params *p, bo
     return EncKernel::SingleU32;
 }
 
-static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p)
+// nslots: blocks (or table entries) of the launch; 0 = unknown (redux_decode_kernel_name: the full-grid choice)
+static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p, uint64_t nslots = 0)
 {
     if (g.gen)
         return p->symbol_bits == 4 ? DecKernel::Gen4 : DecKernel::Gen12;
     if (g.any)
         return DecKernel::Any;
+    // blocks the lock-step decoder does not take (u32 counts, count >= 2^17: one block of any length above all,
+    // redux_decompress) in a launch that leaves SIMDs idle: one block per wave, the model across the lanes
+    // (redux_decode_wave.hpp).  (For u16 blocks it measures 28.9 ms per 64 KiB block against the lock-step decoder's 24.)
+    bool wave = nslots != 0 && nslots <= kWaveDecMaxBlocks && !(g.u16 && !g.fixup);
+#ifdef REDUX_AB
+    if (getenv("REDUX_DECODE_KERNEL"))
+        wave = false;
+#endif
+    if (wave)
+        return g.fixup ? DecKernel::WaveFixup : DecKernel::Wave;
     bool lock = g.u16 && !g.fixup;
 #ifdef REDUX_AB // A/B timing builds only: REDUX_DECODE_KERNEL=generic pins k_decode
     if (getenv("REDUX_DECODE_KERNEL"))
@@ -375,6 +387,8 @@ const char *redux_decode_kernel_name(const redux_params *p, const void *d_out, u
     case DecKernel::Gen4: return "k_decode_gen<4> (4-bit symbols, lock-step, u32 tree in LDS)";
     case DecKernel::Gen12: return "k_decode_gen<12> (12-bit symbols, lock-step; u16 trees in LDS, 16 blocks per wave, or -- 16,384 blocks and more -- u32 trees in the workspace, 64 per wave)";
     case DecKernel::Any: return "k_decode_any (general parameters, one lane per block)";
+    case DecKernel::Wave:
+    case DecKernel::WaveFixup: return "k_decode_wave (one block per wave, cumulative table across the lanes)";
     }
     return "";
 }
@@ -831,7 +845,9 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     a.in_used    = (uint64_t *)d_in_used;
     a.table      = d_table;
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
-    switch (pick_decode_kernel(g, p)) {
+    switch (pick_decode_kernel(g, p, nblocks)) {
+    case DecKernel::Wave: k_decode_wave<false><<<(uint32_t)nblocks, 64, 0, s>>>(a); break;
+    case DecKernel::WaveFixup: k_decode_wave<true><<<(uint32_t)nblocks, 64, 0, s>>>(a); break;
     case DecKernel::LockCb32: k_decode_lock<true><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::Lock: k_decode_lock<false><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::GenericU16: k_decode<true, false><<<grid, 64, 0, s>>>(a); break;

@@ -1313,3 +1313,40 @@ def test_small_grid_kernels_on_large_blocks(rx):
             assert out[int(offs[b]): int(offs[b + 1])].tobytes() == want, (w, bs, b)
         dec, sizes, dst = rx.decompress_blocks(out, offs, bs, w)
         assert not dst.any() and b"".join(dec[b * bs: b * bs + int(sizes[b])].tobytes() for b in range(len(sizes))) == data
+
+
+@pytest.mark.parametrize("params", [(8, 30, 32), (8, 22, 24), (8, 14, 16)])
+def test_wave_decoder_on_damaged_large_blocks(rx, params):
+    """k_decode_wave (one block per wave, the model as a cumulative table across the lanes: redux_decode_wave.hpp) takes the
+    blocks the lock-step decoder cannot -- capacities past 64 KiB -- in small launches.  Intact, bit-flipped, truncated and
+    over-long streams of 70,000 - 200,000 symbols, and garbage: status, decoded length and decoded bytes of every block
+    equal the CPU restatement's, at a capacity some of them overflow."""
+    rnd = np.random.default_rng(sum(params) + 5)
+    cap = 150_000
+    streams = [rnd.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (0, 1, 3, 4, 5, 17, 300, 4001)]  # garbage
+    for i in range(20):
+        kind = i % 5
+        n = int(rnd.integers(cap + 1, 200_000)) if kind == 4 else int(rnd.integers(70_000, 149_000))  # kind 4: more symbols than the capacity
+        src = (rnd.integers(0, 256, n, dtype=np.uint8) >> int(rnd.integers(0, 7))).tobytes()
+        good, _ = ox.compress(src, params)
+        b = bytearray(good)
+        if kind == 0:
+            b[int(rnd.integers(0, len(b)))] ^= 1 << int(rnd.integers(0, 8))         # one flipped bit
+        elif kind == 1:
+            b = b[: int(rnd.integers(len(b) // 2, len(b) + 1))]                       # truncated
+        elif kind == 2:
+            b += rnd.integers(0, 256, int(rnd.integers(1, 9)), dtype=np.uint8).tobytes()  # trailing bytes
+        streams.append(bytes(b))                                                      # kinds 3, 4: intact (4: may overflow the capacity)
+    offs = np.zeros(len(streams) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in streams])
+    dense = np.frombuffer(b"".join(streams), dtype=np.uint8)
+    dec, sizes, status = rx.decompress_blocks(dense, offs, cap, params, check=False)
+    seen = set()
+    for b, stream in enumerate(streams):
+        st, want = _oracle_decode_raw(stream, cap, params)
+        st = 4 if st == 3 else st  # the oracle's writer fails with IoError where the block capacity ends
+        seen.add(st)
+        assert int(status[b]) == st, (b, len(stream), int(status[b]), st)
+        assert int(sizes[b]) == len(want), (b, len(stream), int(sizes[b]), len(want))
+        assert dec[b * cap: b * cap + len(want)].tobytes() == want, (b, len(stream))
+    assert {0, 1, 4} <= seen
