@@ -71,3 +71,33 @@ def test_segments_started_from_prefix_counts_reproduce_the_serial_model(n, nfree
     data = (rng.integers(0, 256, n) >> rng.integers(0, 6)).astype(np.int64)
     data[rng.integers(0, n, max(1, n // 50))] = 255  # the symbol whose upper end is the derived node 256
     assert coop_pairs(data, nfreeze) == serial_pairs(data, nfreeze)
+
+
+def test_wave_decoder_table_search_and_update():
+    """k_decode_wave's model (redux_amd/csrc/redux_decode_wave.hpp) replayed with numpy: four planes of inclusive prefix
+    sums across 64 lanes, the plane picked by three compares against the plane tops, the lane by counting the entries not
+    above the code value, cum(s) / cum(s + 1) read from the neighbouring lanes, the update as +1 on every entry above s."""
+    rng = np.random.default_rng(11)
+    lane = np.arange(64)
+    C = [lane + 1 + 64 * q for q in range(4)]  # cum(l + 64 q + 1), all frequencies 1
+    T = [64, 128, 192]
+    freq = np.ones(256, dtype=np.int64)
+    for step in range(3000):
+        total_data = int(freq.sum())  # = cum(256) = count - 1
+        v = int(rng.integers(0, total_data))  # a code value below the EOF range
+        pq = (v >= T[0]) + (v >= T[1]) + (v >= T[2])
+        X = C[pq]
+        b = int((X <= v).sum())
+        assert b < 64
+        s = 64 * pq + b
+        hi = int(X[b])
+        lo = int(X[b - 1]) if b else (0 if pq == 0 else T[pq - 1])
+        cum = np.concatenate(([0], np.cumsum(freq)))
+        assert (lo, hi) == (int(cum[s]), int(cum[s + 1])) and lo <= v < hi, (step, v, s)
+        if step < 2500:  # (then frozen)
+            freq[s] += 1
+            for q in range(4):
+                C[q] = C[q] + (lane + 64 * q >= s)
+            T = [T[0] + (s < 64), T[1] + (s < 128), T[2] + (s < 192)]
+        for q in range(3):
+            assert T[q] == int(C[q][63])
