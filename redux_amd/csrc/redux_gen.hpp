@@ -40,11 +40,12 @@ namespace redux {
 // are independent, in LDS (8.6 against 6.6 GB/s); below ~16,384 blocks both are 3 x faster in LDS.
 template <int SB, bool INLDS = true>
 struct GenTree {
-    static constexpr bool     kU16    = INLDS && SB > 8;    // u16 nodes, lanes l and l + 8 in one dword
-    static constexpr uint32_t kBlocks = kU16 ? 16u : 64u;   // live lanes (= blocks) per wave
+    static constexpr bool     kU16    = INLDS && SB > 8;    // u16 nodes, lanes l and l + kBlocks / 2 in one dword
+    // live lanes (= blocks) per wave: what 128 KiB of LDS hold as u16 nodes (12-bit symbols: 16, 11: 32, 9 and 10: 64)
+    static constexpr uint32_t kBlocks = kU16 ? (SB >= 12 ? 16u : SB == 11 ? 32u : 64u) : 64u;
     static constexpr uint32_t kRows   = 1u << SB;
     static constexpr uint32_t kMask   = kRows - 1u;
-    static constexpr uint32_t kPitch  = kU16 ? 8u : 64u;    // dwords per row
+    static constexpr uint32_t kPitch  = kU16 ? kBlocks / 2u : 64u; // dwords per row
     static constexpr uint32_t kDwords = kRows * kPitch;     // 4-bit: 4 KiB; 12-bit: 128 KiB of LDS, or 1 MiB of workspace per wave
     static constexpr uint32_t kLdsDwords = INLDS ? kDwords : 64u;
     // u16 nodes hold increments: a node of a block of n symbols receives at most n of them
@@ -55,8 +56,8 @@ struct GenTree {
 
     __device__ __forceinline__ void init(uint32_t *mem, uint32_t lane) // mem: this wave's LDS array / workspace tree
     {
-        base = mem + (kU16 ? (lane & 7u) : lane);
-        sh   = kU16 ? ((lane >> 3) & 1u) * 16u : 0u;
+        base = mem + (kU16 ? (lane & (kPitch - 1u)) : lane);
+        sh   = kU16 ? ((lane / kPitch) & 1u) * 16u : 0u;
     }
     __device__ __forceinline__ uint32_t fetch_add(uint32_t e, uint32_t v) const
     {
@@ -113,37 +114,35 @@ struct GenTree {
     }
 };
 
-// symbol k of a block of `len` bytes at src: read_bits(SB) MSB-first
+// symbol k of a block at src: read_bits(SB) MSB-first (bitio/mod.rs:78-120), in two halves, so that a loop can LOAD the bytes
+// of symbol k one step before it DECODES them (the value that crosses the iteration is the raw load, which nothing waits for
+// until it is decoded).  4-bit symbols: one byte; 12-bit: symbols 2j, 2j+1 share bytes 3j .. 3j+2; any other width: the
+// three bytes from the symbol's first one (a symbol of at most 12 bits starting at bit r <= 7 of a byte ends inside them),
+// the indices clamped to lastb, the last byte the lane may read -- bytes a symbol does not reach do not matter.
 template <int SB>
-__device__ __forceinline__ uint32_t gen_symbol(const uint8_t *src, uint32_t k)
-{
-    if (SB == 4) {
-        const uint32_t byte = src[k >> 1];
-        return (k & 1u) ? (byte & 15u) : (byte >> 4);
-    } else { // SB == 12: symbols 2j, 2j+1 share bytes 3j .. 3j+2
-        const uint32_t i  = k + (k >> 1);
-        const uint32_t b0 = src[i], b1 = src[i + 1];
-        return (k & 1u) ? (((b0 & 15u) << 8) | b1) : ((b0 << 4) | (b1 >> 4));
-    }
-}
-
-// gen_symbol in two halves, so that a loop can LOAD the bytes of symbol k one step before it DECODES them (the value
-// that crosses the iteration is the raw load, which nothing waits for until it is decoded)
-template <int SB>
-__device__ __forceinline__ uint32_t gen_symbol_load(const uint8_t *src, uint32_t k)
+__device__ __forceinline__ uint32_t gen_symbol_load(const uint8_t *src, uint32_t k, uint32_t lastb)
 {
     if (SB == 4)
         return src[k >> 1];
-    const uint32_t i = k + (k >> 1);
-    return (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8);
+    if (SB == 12) {
+        const uint32_t i = k + (k >> 1);
+        return (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8);
+    }
+    const uint32_t i  = (k * SB) >> 3;
+    const uint32_t i1 = i + 1 < lastb ? i + 1 : lastb, i2 = i + 2 < lastb ? i + 2 : lastb;
+    return ((uint32_t)src[i] << 16) | ((uint32_t)src[i1] << 8) | (uint32_t)src[i2];
 }
 template <int SB>
 __device__ __forceinline__ uint32_t gen_symbol_decode(uint32_t raw, uint32_t k)
 {
     if (SB == 4)
         return (k & 1u) ? (raw & 15u) : (raw >> 4);
-    const uint32_t b0 = raw & 0xFFu, b1 = raw >> 8;
-    return (k & 1u) ? (((b0 & 15u) << 8) | b1) : ((b0 << 4) | (b1 >> 4));
+    if (SB == 12) {
+        const uint32_t b0 = raw & 0xFFu, b1 = raw >> 8;
+        return (k & 1u) ? (((b0 & 15u) << 8) | b1) : ((b0 << 4) | (b1 >> 4));
+    }
+    const uint32_t r = (k * SB) & 7u;
+    return (raw >> (24u - SB - r)) & ((1u << SB) - 1u);
 }
 
 struct GenEncArgs {
@@ -210,7 +209,8 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
     const uint32_t last_sym = nsym ? nsym - 1u : 0u;
     const bool     can_load = live && nsym != 0;
     const uint8_t *psrc     = can_load ? src : reinterpret_cast<const uint8_t *>(a.rc); // (always mapped, at least 33 doubles)
-    uint32_t       raw_next = gen_symbol_load<SB>(psrc, 0), k_next = 0;
+    const uint32_t lastb    = can_load ? len - 1u : 2u;
+    uint32_t       raw_next = gen_symbol_load<SB>(psrc, 0, lastb), k_next = 0;
     double         r_next   = rc[0];
     for (uint32_t p = 0; p <= maxsym; p++) {
         const uint32_t nup = p < nfreeze ? p : nfreeze; // wave-uniform
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
         {
             const uint32_t q = p + 1 < last_sym ? p + 1 : last_sym;
             k_next           = can_load ? q : 0u;
-            raw_next         = gen_symbol_load<SB>(psrc, k_next);
+            raw_next         = gen_symbol_load<SB>(psrc, k_next, lastb);
             r_next           = rc[p + 1 < nfreeze ? p + 1 : nfreeze]; // (the table has 32 entries of slack)
         }
         if (live && p < nsym) {
@@ -280,7 +280,8 @@ __global__ void __launch_bounds__(256) k_encode_gen_pair(GenEncArgs a)
         const uint32_t last_sym = nsym ? nsym - 1u : 0u;
         const bool     can_load = live && nsym != 0;
         const uint8_t *psrc     = can_load ? src : reinterpret_cast<const uint8_t *>(a.rc); // (always mapped, at least 33 doubles)
-        uint32_t       raw_next = gen_symbol_load<SB>(psrc, 0), k_next = 0;
+        const uint32_t lastb    = can_load ? len - 1u : 2u;
+        uint32_t       raw_next = gen_symbol_load<SB>(psrc, 0, lastb), k_next = 0;
         uint2         *my       = ring[wave];
         for (uint32_t t = 0; t < nper; t++) {
 #pragma unroll
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(256) k_encode_gen_pair(GenEncArgs a)
                 {
                     const uint32_t q = p + 1 < last_sym ? p + 1 : last_sym;
                     k_next           = can_load ? q : 0u;
-                    raw_next         = gen_symbol_load<SB>(psrc, k_next);
+                    raw_next         = gen_symbol_load<SB>(psrc, k_next, lastb);
                 }
                 uint32_t lo = 0, hi = 0;
                 if (live && p < nsym) {

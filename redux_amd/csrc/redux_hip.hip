@@ -7,7 +7,8 @@
 //   redux_pack.hpp     k_scan_sizes, k_compact: slots -> dense stream + offsets
 //   redux_coop.hpp     k_coop_model, k_coop_chain: small grids, a block's model computed by 64 lanes
 //   redux_any.hpp      general Parameters (symbol_bits <= 16, code_bits <= 63), one lane per block
-//   redux_gen.hpp      k_encode_gen / k_decode_gen: 4- and 12-bit symbols (code_bits <= 32) in lock-step form
+//   redux_gen.hpp      k_encode_gen / k_encode_gen_pair: symbol widths 1 .. 12 other than 8 (code_bits <= 32) in lock-step form
+//   redux_decode_cells.hpp  k_decode_cells: their decoder, the tree as cells of four levels
 //   redux_synth.hpp    k_gen_iid / k_gen_zipf
 //   redux_static.hpp   k_encode_static / k_decode_static: the coder core under a fixed frequency table
 // This file holds the general-parameter kernels' launch shims, the workspace geometry and the
@@ -21,6 +22,7 @@
 #include "redux_decode.hpp"
 #include "redux_decode_adaptive.hpp"
 #include "redux_decode_wave.hpp"
+#include "redux_decode_cells.hpp"
 #include "redux_pack.hpp"
 #include "redux_coop.hpp"
 #include "redux_synth.hpp"
@@ -136,24 +138,45 @@ static int check_params(const redux_params *p)
 }
 
 static bool is_any(const redux_params *p) { return p->symbol_bits != 8 || p->code_bits > 32; }
-// the widths src/model/tests.rs exercises besides 8: lock-step kernels (symbol index and byte offsets stay in 32 bits)
-// Blocks of at most 4 MiB: the kernels index a reciprocal table by the symbol number (one f64 per symbol of a block: 64 MiB
-// for 4 MiB of 4-bit symbols) and address 64 slots / 64 blocks with 32-bit lane offsets; a bigger block -- whole-stream
-// mode, redux_compress / redux_decompress of a large buffer or with a large output capacity -- is one lane's serial chain
-// anyway and runs on the one-lane kernels, which have neither limit.
-// The 12-bit decoder keeps its trees in LDS (16 blocks per CU) on small grids and in the workspace (64 per wave, many waves per
-// CU) on large ones: see GenTree.
-static bool gen12_decode_in_workspace(const redux_params *p, uint64_t nblocks) { return p->symbol_bits == 12 && nblocks >= 16384; }
-
-// 12-bit symbols: the tree lives in LDS as u16 increments (redux_gen.hpp): blocks of at most 65535 symbols.
+// Symbol widths 1 .. 12 other than 8 with code_bits <= 32 -- the widths src/model/tests.rs exercises besides 8 (4 and 12)
+// and everything between -- have lock-step kernels: the encoders of redux_gen.hpp, the cell decoder of
+// redux_decode_cells.hpp.  Their limits, in symbols of a block (a bigger block -- whole-stream mode above all -- is one
+// lane's serial chain anyway and runs on the one-lane kernels, which have none):
+//   * 4 MiB: the kernels index a reciprocal table by the symbol number and address 64 slots / 64 blocks with 32-bit lane offsets;
+//   * symbol_bits >= 9: u16 tree nodes holding lowbit + increments: at most 65535 - 2^(symbol_bits - 1) updates of the model
+//     (symbols of a block, or fewer if the model freezes first: 12-bit symbols, 20 frequency bits: blocks of 95,230 bytes);
+//   * symbol_bits <= 7: the decoder's lock-step loop runs while the count is below 2^17 (no quotient fix-up): a model that
+//     freezes below that, or blocks of at most 2^17 + 64 - (2^symbol_bits + 1) symbols -- what a 64 KiB block of 4-bit
+//     symbols has;
+//   * 4-bit symbols beyond that: k_encode_gen<4> and the per-level decoder k_decode_gen<4>.
+static uint64_t gen_updates(const redux_params *p, uint32_t block_size) // increments a tree node of a block can receive
+{
+    const uint64_t nsym    = (uint64_t)block_size * 8 / p->symbol_bits;
+    const uint64_t nfreeze = ((1ull << p->freq_bits) - 1) - ((1ull << p->symbol_bits) + 1);
+    return nsym < nfreeze ? nsym : nfreeze;
+}
+// the cell decoder takes the block: see above
+static bool gen_decode_cells(const redux_params *p, uint32_t block_size)
+{
+    const uint64_t count0 = (1ull << p->symbol_bits) + 1;
+    if (p->symbol_bits >= 8)
+        return gen_updates(p, block_size) + (1ull << (p->symbol_bits - 1)) <= 65535;
+    const uint64_t nfreeze = ((1ull << p->freq_bits) - 1) - count0;
+    return count0 + nfreeze < (1ull << 17) || (uint64_t)block_size * 8 / p->symbol_bits + count0 <= (1ull << 17) + 64;
+}
 static bool is_gen(const redux_params *p, uint32_t block_size)
 {
-    if (p->code_bits > 32)
+    if (p->code_bits > 32 || p->symbol_bits == 8 || p->symbol_bits > 12 || block_size > (1u << 22))
         return false;
-    if (p->symbol_bits == 4)
-        return block_size <= (1u << 22);
-    return p->symbol_bits == 12 && (uint64_t)block_size * 8 / 12 <= GenTree<12>::kMaxSymbols;
+    return p->symbol_bits == 4 || gen_decode_cells(p, block_size);
 }
+// 11- and 12-bit symbols: the bottom cells (4 / 8 KiB per block) live in LDS on small grids -- 32 / 16 blocks per wave, one
+// wave per CU -- and in the workspace on large ones (64 blocks per wave, four waves per CU): redux_decode_cells.hpp
+static bool gen_decode_in_workspace(const redux_params *p, uint64_t nblocks)
+{
+    return (p->symbol_bits == 12 && nblocks >= 16384) || (p->symbol_bits == 11 && nblocks >= 32768);
+}
+static uint64_t gen_decode_tree_bytes(const redux_params *p) { return p->symbol_bits == 12 ? CellGeom<12, 64, true>::kTreeBytes : CellGeom<11, 64, true>::kTreeBytes; }
 
 static uint64_t slot_cap_for(const redux_params *p, uint32_t block_size)
 {
@@ -270,8 +293,8 @@ static uint32_t cu_count()
 
 // ---- which kernel a call runs: ONE decision, used by the launch code and reported by
 // redux_encode_kernel_name / redux_decode_kernel_name (bench.py's roofline.kernel) ------------
-enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Gen4, Gen12, Any, CoopCb32, Coop };
-enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Gen4, Gen12, Any, Wave, WaveFixup };
+enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Gen, GenPair, Any, CoopCb32, Coop };
+enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Cells, CellsWorkspace, Gen4, Any, Wave, WaveFixup };
 
 // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset; otherwise
 // (giant blocks, whole-stream mode) one block per wave.
@@ -283,7 +306,7 @@ static uint32_t encode_lanes(const Geometry &g, uint32_t block_size)
 static EncKernel pick_encode_kernel(const Geometry &g, const redux_params *p, bool aligned16, uint32_t block_size)
 {
     if (g.gen)
-        return p->symbol_bits == 4 ? EncKernel::Gen4 : EncKernel::Gen12;
+        return p->symbol_bits < 8 ? EncKernel::Gen : EncKernel::GenPair;
     if (g.any)
         return EncKernel::Any;
     bool coop = g.coop;
@@ -308,10 +331,13 @@ static EncKernel pick_encode_kernel(const Geometry &g, const redux_params *p, bo
 }
 
 // nslots: blocks (or table entries) of the launch; 0 = unknown (redux_decode_kernel_name: the full-grid choice)
-static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p, uint64_t nslots = 0)
+static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p, uint64_t nslots = 0, uint32_t block_size = 0)
 {
-    if (g.gen)
-        return p->symbol_bits == 4 ? DecKernel::Gen4 : DecKernel::Gen12;
+    if (g.gen) {
+        if (!gen_decode_cells(p, block_size))
+            return DecKernel::Gen4;
+        return gen_decode_in_workspace(p, nslots ? nslots : ~0ull) ? DecKernel::CellsWorkspace : DecKernel::Cells;
+    }
     if (g.any)
         return DecKernel::Any;
     // blocks the lock-step decoder does not take (u32 counts, count >= 2^17: one block of any length above all,
@@ -365,8 +391,16 @@ const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, ui
     case EncKernel::SingleU16: return "k_encode<true, false> (u16 tree, one wave per 64 blocks)";
     case EncKernel::SingleU16Fixup: return "k_encode<true, true> (u16 tree, one wave per 64 blocks, quotient fix-up)";
     case EncKernel::SingleU32: return "k_encode<false, true> (u32 tree)";
-    case EncKernel::Gen4: return "k_encode_gen<4> (4-bit symbols, lock-step, u32 tree in LDS)";
-    case EncKernel::Gen12: return "k_encode_gen_pair<12> (12-bit symbols, lock-step, u16 tree in LDS, 16 blocks per workgroup: three model waves + coder wave)";
+    case EncKernel::Gen: {
+        static const char *const names[8] = {"", "k_encode_gen<1>", "k_encode_gen<2>", "k_encode_gen<3>", "k_encode_gen<4>", "k_encode_gen<5>",
+                                              "k_encode_gen<6>", "k_encode_gen<7>"};
+        return names[p->symbol_bits]; // (lock-step, u32 tree in LDS, one wave per 64 blocks)
+    }
+    case EncKernel::GenPair: {
+        // lock-step, u16 tree in LDS, one workgroup per 64 / 64 / 32 / 16 blocks: three model waves + a coder wave
+        static const char *const names[4] = {"k_encode_gen_pair<9>", "k_encode_gen_pair<10>", "k_encode_gen_pair<11>", "k_encode_gen_pair<12>"};
+        return names[p->symbol_bits - 9];
+    }
     case EncKernel::Any: return "k_encode_any (general parameters, one lane per block)";
     }
     return "";
@@ -378,14 +412,22 @@ const char *redux_decode_kernel_name(const redux_params *p, const void *d_out, u
         return "";
     (void)d_out; // every decoder takes any alignment (it only picks the store width inside the kernel)
     const Geometry g = geometry(p, block_size, block_size);
-    switch (pick_decode_kernel(g, p)) {
+    switch (pick_decode_kernel(g, p, 0, block_size)) {
     case DecKernel::LockCb32: return "k_decode_lock<true> (u16 tree, one wave per 64 blocks, code_bits 32)";
     case DecKernel::Lock: return "k_decode_lock<false> (u16 tree, one wave per 64 blocks)";
     case DecKernel::GenericU16: return "k_decode<true, false> (u16 tree, per-lane control flow)";
     case DecKernel::GenericU16Fixup: return "k_decode<true, true> (u16 tree, quotient fix-up)";
     case DecKernel::GenericU32: return "k_decode<false, true> (u32 tree)";
-    case DecKernel::Gen4: return "k_decode_gen<4> (4-bit symbols, lock-step, u32 tree in LDS)";
-    case DecKernel::Gen12: return "k_decode_gen<12> (12-bit symbols, lock-step; u16 trees in LDS, 16 blocks per wave, or -- 16,384 blocks and more -- u32 trees in the workspace, 64 per wave)";
+    case DecKernel::Gen4: return "k_decode_gen<4> (4-bit symbols beyond 2^17 per block: per-level walk, u32 tree in LDS)";
+    case DecKernel::Cells:
+    case DecKernel::CellsWorkspace: {
+        // lock-step, the tree as cells of four levels: all of them in LDS, or (11- and 12-bit symbols on a grid that fills the
+        // chip: redux_decode_kernel_name answers for that grid) the bottom ones in the workspace
+        static const char *const names[13] = {"", "k_decode_cells<1>", "k_decode_cells<2>", "k_decode_cells<3>", "k_decode_cells<4>",
+                                               "k_decode_cells<5>", "k_decode_cells<6>", "k_decode_cells<7>", "", "k_decode_cells<9>",
+                                               "k_decode_cells<10>", "k_decode_cells<11>", "k_decode_cells<12>"};
+        return names[p->symbol_bits];
+    }
     case DecKernel::Any: return "k_decode_any (general parameters, one lane per block)";
     case DecKernel::Wave:
     case DecKernel::WaveFixup: return "k_decode_wave (one block per wave, cumulative table across the lanes)";
@@ -472,10 +514,17 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
         ga.code_bits  = p->code_bits;
         // (64 slots / blocks within a 32-bit lane offset: geometry())
         k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)(ws + g.off_rc), g.rc_n, (1u << p->symbol_bits) + 1u);
-        if (p->symbol_bits == 4)
-            k_encode_gen<4><<<(uint32_t)((g.nblocks + 63) / 64), 64, 0, s>>>(ga);
-        else
-            k_encode_gen_pair<12><<<(uint32_t)((g.nblocks + GenTree<12>::kBlocks - 1) / GenTree<12>::kBlocks), 256, 0, s>>>(ga);
+        const uint32_t grid64 = (uint32_t)((g.nblocks + 63) / 64);
+        switch (p->symbol_bits) {
+#define REDUX_GEN_ENC(SB) case SB: k_encode_gen<SB><<<grid64, 64, 0, s>>>(ga); break;
+#define REDUX_GEN_ENC_PAIR(SB)                                                                                         \
+    case SB: k_encode_gen_pair<SB><<<(uint32_t)((g.nblocks + GenTree<SB>::kBlocks - 1) / GenTree<SB>::kBlocks), 256, 0, s>>>(ga); break;
+            REDUX_GEN_ENC(1) REDUX_GEN_ENC(2) REDUX_GEN_ENC(3) REDUX_GEN_ENC(4) REDUX_GEN_ENC(5) REDUX_GEN_ENC(6) REDUX_GEN_ENC(7)
+            REDUX_GEN_ENC_PAIR(9) REDUX_GEN_ENC_PAIR(10) REDUX_GEN_ENC_PAIR(11) REDUX_GEN_ENC_PAIR(12)
+#undef REDUX_GEN_ENC
+#undef REDUX_GEN_ENC_PAIR
+        default: return REDUX_UNSUPPORTED;
+        }
         HIP_TRY(hipGetLastError());
         return REDUX_OK;
     }
@@ -550,8 +599,8 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
     case EncKernel::SingleU16: k_encode<true, false><<<grid, 64, 0, s>>>(a); break;
     case EncKernel::SingleU16Fixup: k_encode<true, true><<<grid, 64, 0, s>>>(a); break;
     case EncKernel::SingleU32: k_encode<false, true><<<grid, 64, 0, s>>>(a); break;
-    case EncKernel::Gen4:
-    case EncKernel::Gen12:
+    case EncKernel::Gen:
+    case EncKernel::GenPair:
     case EncKernel::Any: break; // handled above
     }
     HIP_TRY(hipGetLastError());
@@ -747,9 +796,9 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
     if (check_params(p) != REDUX_OK || block_size == 0)
         return 0;
     const Geometry g = geometry(p, block_size, block_size);
-    if (g.gen) // (12-bit symbols on a large grid decode with their trees in the workspace: gen12_decode_in_workspace)
+    if (g.gen) // (11- and 12-bit symbols on a large grid decode with their bottom cells in the workspace: gen_decode_in_workspace)
         return align_up((uint64_t)g.rc_n * 8, 256) +
-               (gen12_decode_in_workspace(p, nblocks) ? (nblocks + 63) / 64 * (uint64_t)GenTree<12, false>::kDwords * 4 : 0);
+               (gen_decode_cells(p, block_size) && gen_decode_in_workspace(p, nblocks) ? (nblocks + 63) / 64 * 64 * gen_decode_tree_bytes(p) : 0);
     if (g.any)
         return (nblocks ? nblocks : 1) * g.tree_bytes;
     return align_up((uint64_t)g.rc_n * 8, 256);
@@ -793,14 +842,30 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         ga.nfreeze    = g.nfreeze;
         ga.code_bits  = p->code_bits;
         k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)d_workspace, g.rc_n, (1u << p->symbol_bits) + 1u);
-        if (p->symbol_bits == 4)
-            k_decode_gen<4><<<(uint32_t)((nblocks + 63) / 64), 64, 0, s>>>(ga);
-        else if (gen12_decode_in_workspace(p, nblocks)) {
-            const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
-            HIP_TRY(hipMemsetAsync(ga.trees, 0, (uint64_t)grid * GenTree<12, false>::kDwords * 4, s)); // every tree starts at all-ones frequencies
-            k_decode_gen<12, false><<<grid, 64, 0, s>>>(ga);
-        } else
-            k_decode_gen<12><<<(uint32_t)((nblocks + GenTree<12>::kBlocks - 1) / GenTree<12>::kBlocks), 64, 0, s>>>(ga);
+        const uint32_t grid64 = (uint32_t)((nblocks + 63) / 64);
+        switch (pick_decode_kernel(g, p, nblocks, block_size)) {
+        case DecKernel::Gen4: k_decode_gen<4><<<grid64, 64, 0, s>>>(ga); break;
+        case DecKernel::CellsWorkspace: {
+            // every tree starts at all-ones frequencies: a node = its lowbit
+            const uint64_t npieces = (uint64_t)grid64 * 64 * gen_decode_tree_bytes(p) / 16;
+            k_fill_cells16<<<(uint32_t)((npieces + 255) / 256), 256, 0, s>>>((cl_u32x4 *)ga.trees, npieces);
+            if (p->symbol_bits == 12)
+                k_decode_cells<12, 64, true><<<grid64, 64, 0, s>>>(ga);
+            else
+                k_decode_cells<11, 64, true><<<grid64, 64, 0, s>>>(ga);
+            break;
+        }
+        case DecKernel::Cells:
+            switch (p->symbol_bits) {
+#define REDUX_GEN_DEC(SB, LANES) case SB: k_decode_cells<SB, LANES, false><<<(uint32_t)((nblocks + LANES - 1) / LANES), LANES, 0, s>>>(ga); break;
+                REDUX_GEN_DEC(1, 64) REDUX_GEN_DEC(2, 64) REDUX_GEN_DEC(3, 64) REDUX_GEN_DEC(4, 64) REDUX_GEN_DEC(5, 64) REDUX_GEN_DEC(6, 64)
+                REDUX_GEN_DEC(7, 64) REDUX_GEN_DEC(9, 64) REDUX_GEN_DEC(10, 64) REDUX_GEN_DEC(11, 32) REDUX_GEN_DEC(12, 16)
+#undef REDUX_GEN_DEC
+            default: return REDUX_UNSUPPORTED;
+            }
+            break;
+        default: return REDUX_UNSUPPORTED;
+        }
         if (d_summary)
             k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
         HIP_TRY(hipGetLastError());
@@ -854,7 +919,8 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     case DecKernel::GenericU16Fixup: k_decode<true, true><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::GenericU32: k_decode<false, true><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::Gen4:
-    case DecKernel::Gen12:
+    case DecKernel::Cells:
+    case DecKernel::CellsWorkspace:
     case DecKernel::Any: break; // handled above
     }
     if (d_summary) // (with a block table nblocks counts its entries: statuses are per block)

@@ -923,7 +923,14 @@ def test_kernel_names_follow_the_dispatch(rx):
     assert enc((12, 14, 16), 0, 1 << 20, 65536).startswith("k_encode_gen_pair<12>")
     assert enc((4, 10, 16), 0, 1 << 20, 65536).startswith("k_encode_gen<4>")
     assert enc((12, 20, 44), 0, 1 << 20, 65536).startswith("k_encode_any")              # code_bits > 32
-    assert enc((5, 10, 16), 0, 1 << 20, 65536).startswith("k_encode_any")
+    assert enc((5, 10, 16), 0, 1 << 20, 65536).startswith("k_encode_gen<5>")           # every width 1 .. 12 has a lock-step kernel
+    assert enc((11, 21, 32), 0, 1 << 20, 65536).startswith("k_encode_gen_pair<11>")
+    assert enc((13, 21, 32), 0, 1 << 20, 65536).startswith("k_encode_any")
+    assert dec((5, 27, 32), 65536).startswith("k_decode_cells<5>")
+    assert dec((11, 21, 32), 65536).startswith("k_decode_cells<11>")
+    assert dec((4, 28, 32), 65536).startswith("k_decode_cells<4>")
+    assert dec((4, 28, 32), 1 << 20).startswith("k_decode_gen<4>")                       # count passes 2^17 early: the per-level walk
+    assert dec((13, 21, 32), 65536).startswith("k_decode_any")
     assert dec((8, 30, 32), 65536).startswith("k_decode_lock<true>")
     assert dec((8, 22, 24), 65536).startswith("k_decode_lock<false>")
     assert dec((8, 30, 32), 1001, 2).startswith("k_decode_lock<true>")
@@ -997,9 +1004,12 @@ def test_host_abi_from_two_threads_and_release(rx):
     assert split(out, offs) == want
 
 
-@pytest.mark.parametrize("params", [(4, 10, 16), (4, 22, 24), (4, 28, 32), (12, 14, 16), (12, 18, 30), (12, 20, 32)])
+@pytest.mark.parametrize("params", [(4, 10, 16), (4, 22, 24), (4, 28, 32), (12, 14, 16), (12, 18, 30), (12, 20, 32),
+                                    (1, 3, 5), (2, 10, 16), (3, 12, 14), (5, 27, 32), (6, 9, 12), (7, 24, 30), (9, 11, 13), (10, 22, 32),
+                                    (11, 21, 32)])
 def test_lockstep_kernels_for_4_and_12_bit_symbols(rx, params):
-    """The widths src/model/tests.rs:95-251 exercises besides 8, on the lock-step kernels of redux_gen.hpp:
+    """The widths src/model/tests.rs:95-251 exercises besides 8 (4 and 12) and the ones between, on the lock-step kernels of
+    redux_gen.hpp (encode) and redux_decode_cells.hpp (decode):
     64 KiB blocks (131,072 resp. 43,690 symbols: the model freezes inside the block for the narrow frequency
     widths, count passes 2^17 for 4-bit symbols), ragged tail, 70 blocks = two waves, streams bit-exact with the
     oracle, decode equal to the oracle's decode (12-bit symbols: the trailing 8 bits of a 64 KiB block are dropped)."""
@@ -1007,7 +1017,7 @@ def test_lockstep_kernels_for_4_and_12_bit_symbols(rx, params):
     from redux_amd import _lib
     p = _lib.Params(*params)
     assert _lib.lib().redux_encode_kernel_name(C.byref(p), None, 1 << 20, BLOCK).decode().startswith(("k_encode_gen<%d>" % params[0], "k_encode_gen_pair<%d>" % params[0]))
-    assert _lib.lib().redux_decode_kernel_name(C.byref(p), None, BLOCK).decode().startswith(f"k_decode_gen<{params[0]}>")
+    assert _lib.lib().redux_decode_kernel_name(C.byref(p), None, BLOCK).decode().startswith(f"k_decode_cells<{params[0]}>")
     rng = np.random.default_rng(params[0] * 100 + params[1])
     text = open(os.path.join(GOLDEN, "corpora", "large", "world192.txt"), "rb").read()
     data = (text + rng.integers(0, 256, 70 * BLOCK - len(text) + 4321, dtype=np.uint8).tobytes())
@@ -1191,15 +1201,15 @@ def test_host_calls_on_two_contexts_of_one_device(rx):
 def test_gen_kernels_hand_large_blocks_to_the_one_lane_kernels(rx):
     """Blocks beyond what the lock-step kernels for 4- and 12-bit symbols take (4-bit blocks of 12 - 256 MiB used to come
     back Unsupported once 64 slots no longer fitted a 32-bit lane offset).  The limits are now part of the kernel choice -- 4 MiB
-    for 4-bit symbols, 65,535 symbols = 98,302 bytes for 12-bit ones (u16 tree nodes in LDS) -- and the one-lane kernels code what
+    for 4-bit symbols, 63,487 symbols = 95,230 bytes for 12-bit ones (u16 tree nodes holding lowbit + increments) -- and the one-lane kernels code what
     is above them.  Checked here just above the 12-bit limit (the 4-bit one takes a minute on one lane)."""
     from redux_amd import _lib
     import ctypes as C
     rng = np.random.default_rng(5)
-    data = (rng.integers(0, 256, 98_304 + 2000, dtype=np.uint8) & 0x3F).tobytes()
+    data = (rng.integers(0, 256, 95_232 + 2000, dtype=np.uint8) & 0x3F).tobytes()
     cp = _lib.Params(12, 20, 32)
     assert b"k_encode_any" in _lib.lib().redux_encode_kernel_name(C.byref(cp), None, len(data), len(data))
-    assert b"k_encode_gen" in _lib.lib().redux_encode_kernel_name(C.byref(cp), None, 98_302, 98_302)
+    assert b"k_encode_gen" in _lib.lib().redux_encode_kernel_name(C.byref(cp), None, 95_230, 95_230)
     cp4 = _lib.Params(4, 22, 24)
     assert b"k_encode_any" in _lib.lib().redux_encode_kernel_name(C.byref(cp4), None, (4 << 20) + 1, (4 << 20) + 1)
     assert b"k_encode_gen" in _lib.lib().redux_encode_kernel_name(C.byref(cp4), None, 4 << 20, 4 << 20)
@@ -1219,7 +1229,7 @@ def test_gen_kernels_hand_large_blocks_to_the_one_lane_kernels(rx):
 
 
 def test_12_bit_decoder_on_a_large_grid_uses_workspace_trees(rx):
-    """16,384 blocks and more: k_decode_gen<12, false> (u32 trees in the workspace, 64 blocks per wave) instead of the LDS form.
+    """16,384 blocks and more: k_decode_cells<12, 64, true> (bottom cells in the workspace, 64 blocks per wave) instead of the LDS form.
     Small blocks keep it quick: streams against the oracle on a sample, everything decoded back."""
     rng = np.random.default_rng(21)
     bs, nb = 96, 16400 + 37

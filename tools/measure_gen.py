@@ -39,5 +39,5 @@ for params in ((4, 28, 32), (5, 27, 32), (12, 20, 32), (11, 21, 32)):
     res["%d,%d,%d" % params] = {"encode_MBps": round(n / e[0].elapsed_time(e[1]) / 1e3, 1), "decode_MBps": round(n / e[1].elapsed_time(e[2]) / 1e3, 1),
                                 "ratio": round(total / n, 4)}
 res["blocks"] = nb
-res["note"] = "4 and 12: k_encode_gen / k_decode_gen (lock-step); 5 and 11: k_encode_any / k_decode_any (one lane per block, the reference's loops)"
+res["note"] = "k_encode_gen / k_encode_gen_pair (redux_gen.hpp) and k_decode_cells (redux_decode_cells.hpp): lock-step kernels for every width"
 print(json.dumps(res))
