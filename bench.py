@@ -23,7 +23,8 @@ Extra objects on the JSON line:
   cpu_baseline  the CPU oracle (C restatement of the reference, kind "port") on a bounded
                 prefix of the same workload, on this box's host cores, rank 0 at N=1 only.
   decode        (rank 0, after the timed steps, not part of `value`) one timed pass of the
-                decoder over the dense output, checked equal to the input on the device.
+                decoder over the dense output, checked equal to the input on the device; `traffic`
+                borrowed from profiles/traffic.json under the same source-hash gate.
   small_launch  (rank 0 at N=1, not part of `value`) encode and decode of the first 62 blocks
                 alone -- a launch where one block's serial chain is the whole time; its streams
                 are checked equal to the same blocks' streams of the full launch.
@@ -205,8 +206,8 @@ def main():
                 return ent, ent.get("source", f"profiles/{fname}")
         return None, f"profiles/{fname} has no entry for {want}"
 
-    tent, traffic_src = borrowed("traffic.json", {"workload": args.workload, "blocks": nblocks})
-    traffic = tent.get("hbm_bytes_per_launch") if tent and tent.get("kernel", "") in kname else None
+    tent, traffic_src = borrowed("traffic.json", {"workload": args.workload, "blocks": nblocks, "kernel": kname.split(" (")[0]})
+    traffic = tent.get("hbm_bytes_per_launch") if tent else None
     ient, issue_src = borrowed("issue.json", {"workload": args.workload, "blocks": nblocks, "kernel": kname.split(" (")[0]})
     issue = ({k: ient[k] for k in ("valu_per_symbol", "lds_per_symbol", "salu_per_symbol", "cycles_per_symbol", "valu_issue_frac")}
              if ient else None)
@@ -272,7 +273,9 @@ def main():
         dissue = ({k: dent[k] for k in ("valu_per_symbol", "lds_per_symbol", "salu_per_symbol", "cycles_per_symbol", "valu_issue_frac")}
                   if dent else {"valu_per_symbol": None, "cycles_per_symbol": None, "valu_issue_frac": None})
         dissue["source"] = dsrc
+        dtent, dtraffic_src = borrowed("traffic.json", {"workload": args.workload, "blocks": nblocks, "kernel": dname.split(" (")[0]})
         line["decode"] = {"kernel": dname, "ms": round(dms, 3),
+                          "traffic": dtent.get("hbm_bytes_per_launch") if dtent else None, "traffic_source": dtraffic_src,
                           "MBps": round(n / (dms * 1e-3) / 1e6, 1),
                           "algorithmic_GBps": round(algo_bytes / (dms * 1e-3) / 1e9, 2),
                           "frac": round(algo_bytes / (dms * 1e-3) / HBM_PEAK, 5), "issue": dissue, "roundtrip_equal": True}

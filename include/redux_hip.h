@@ -194,9 +194,17 @@ int redux_decode_blocks_dev(const redux_params *p, const void *d_in, const void 
                             void *d_out_sizes /* u32[nblocks] */, void *d_block_status, void *d_summary,
                             void *d_workspace, uint64_t workspace_bytes, void *stream);
 
-/* The `_v` calls with everything in device memory.  d_table: redux_block[nblocks] in launch order
+/* The `_v` calls with everything in device memory.  d_table: redux_block[nentries] in launch order
  * (redux_block_table_v builds one; any order is valid, a wave's 64 consecutive entries run in
- * lock-step for as long as its shortest block lasts).  Encode: entry.offset is the block's first
+ * lock-step for as long as its shortest block lasts).  The table is CHECKED on the device before any
+ * coder kernel reads it (one thread per entry, tens of microseconds; the kernels then read a copy in the
+ * workspace, the caller's table is never written): an entry must be idle (index REDUX_BLOCK_IDLE) or have
+ * index < nblocks, an index no other entry has, length <= block_size, offset + length <= in_bytes /
+ * out_bytes and, under REDUX_V_ALIGNED16, offset a multiple of 16.  An entry that fails is treated as
+ * idle -- nothing is read or written through it --, a block that no valid entry codes comes back with
+ * size 0 and status REDUX_INVALID_INPUT, and d_summary[0] is REDUX_INVALID_INPUT (the return value covers
+ * argument and launch errors only, as everywhere: the call is stream-ordered).  As the reference's
+ * surface never writes out of bounds (bitio/mod.rs:148-198 returns Err), neither does a bad table.  Encode: entry.offset is the block's first
  * byte in d_in (in_bytes = size of that buffer, below 4 GiB), entry.length its size.  Decode:
  * entry.offset is where the block's output starts in d_out (out_bytes = size of that buffer),
  * entry.length the room it has there.  flags: REDUX_V_ALIGNED16 promises that d_in / d_out and

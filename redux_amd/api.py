@@ -163,6 +163,8 @@ def decompress_blocks(streams, offsets, block_size, params=(8, 30, 32), check=Tr
     a = _u8(streams)
     offs = np.ascontiguousarray(offsets, dtype=np.uint64)
     nb = len(offs) - 1
+    if nb < 0 or (nb >= 0 and len(offs) and (int(offs[-1]) > len(a) or bool((offs[1:] < offs[:-1]).any()))):
+        raise InvalidInput()  # (the C call reads streams[offsets[b] .. offsets[b + 1]) from caller memory)
     L = _lib.lib()
     cp = P._c()
     _raise(L.redux_device_supports(C.byref(cp)))
@@ -255,6 +257,9 @@ def decompress_blocks_v(streams, offsets, lengths, block_size, params=(8, 30, 32
         raise InvalidInput()
     nb = L.redux_block_count_v(lens.ctypes.data, len(lens), block_size)
     if nb != len(offs) - 1:
+        raise InvalidInput()
+    # the C call copies streams[offsets[0] .. offsets[nb]) from caller memory: they must lie inside `streams`, in order
+    if int(offs[0]) != 0 or int(offs[-1]) > len(a) or bool((offs[1:] < offs[:-1]).any()):
         raise InvalidInput()
     out_off = np.zeros(len(lens), dtype=np.uint64)
     out_off[1:] = np.cumsum(lens)[:-1]

@@ -280,6 +280,7 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
     uint32_t stored = 0; // bytes [0, stored) of the block are in memory
     uint32_t staged = 0; // bytes [stored, staged) are whole dwords waiting in oq (newest in .w)
     uint4    oq     = make_uint4(0, 0, 0, 0);
+    uint4    oqp    = make_uint4(0, 0, 0, 0); // the lock-step loop: the turn before oq's, while it waits for its partner
     uint32_t p      = 0;
     DecTop   T      = dec_top_new();
 
@@ -349,8 +350,16 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                 // must find nothing younger than a group in flight): chunk -> ring, output store, next request
                 retire();
                 if (G == 0 && p != 0) {
-                    if ((int32_t)S.dflag >= 0)
+                    // Output: the sixteen bytes of the turn before this one wait in oq.  They leave TOGETHER with the turn
+                    // before them, as two adjacent 16-byte stores every second turn: one 16-byte store per turn lands in
+                    // half a 32-byte sector, and the L2's background cleaning writes such a sector back before its other
+                    // half arrives -- twice the decoded bytes in fabric writes (WRITE_SIZE 8.43e6 KiB for 4 GiB).
+                    if (p & 16u) // (wave-uniform)
+                        oqp = oq;
+                    else if ((int32_t)S.dflag >= 0) {
+                        *reinterpret_cast<uint4 *>(dst + (p - 32)) = oqp;
                         *reinterpret_cast<uint4 *>(dst + (p - 16)) = oq;
+                    }
                 }
                 request();
                 if (GEN) { // (the table ends 32 entries behind the freeze point)
@@ -536,6 +545,9 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
                         S.n_out  = fin ? p + 4 * G + K : S.n_out;
                         S.dflag  = fin ? 0x80000000u : S.dflag;
                         livemask = fin ? 0x7FFFFFFFu : livemask;
+                        // (the turn before this one, if it is still waiting for its partner: see the top of the turn)
+                        if ((p & 16u) && fin)
+                            *reinterpret_cast<uint4 *>(dst + (p - 16)) = oqp;
                         // the lane's unstored output in the form the end of the kernel writes out: G whole dwords in the
                         // LAST components of oq, the K bytes of the current one in obuf
                         stored = fin ? p : stored;
@@ -576,6 +588,8 @@ __device__ __forceinline__ void decode_adaptive_body(const DecArgs &a, uint32_t 
 #undef REDUX_AD_MASK
 #undef REDUX_AD_PICK
         if (p != 0 && (int32_t)S.dflag >= 0) {
+            if ((p & 16u) == 0) // the last turn's partner is still waiting too
+                *reinterpret_cast<uint4 *>(dst + (p - 32)) = oqp;
             *reinterpret_cast<uint4 *>(dst + (p - 16)) = oq;
             stored = p;
             staged = p;

@@ -24,6 +24,7 @@
 #include "redux_decode_wave.hpp"
 #include "redux_decode_cells.hpp"
 #include "redux_pack.hpp"
+#include "redux_table.hpp"
 #include "redux_coop.hpp"
 #include "redux_synth.hpp"
 #include "redux_static.hpp"
@@ -122,7 +123,7 @@ struct Geometry {
     bool     coop;       // small grid: k_coop_model + k_coop_chain (redux_coop.hpp), (low, high) pairs in the workspace
     uint32_t pair_width; // ... in rows of this many lanes
     // workspace layout (encode)
-    uint64_t off_rc, off_sizes, off_mode, off_slots, off_trees, off_pairs, total;
+    uint64_t off_rc, off_sizes, off_mode, off_slots, off_trees, off_table, off_seen, off_pairs, total;
 };
 
 static int check_params(const redux_params *p)
@@ -253,7 +254,10 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.off_slots = g.off_mode + 256 + kClaimWords * 4; // mode word, then k_encode_pair's role book
     // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode
     g.off_trees = align_up(g.off_slots + ((g.nblocks + 63) / 64 * 64 + 1) * g.slot_bytes + (g.nblocks + 63) / 64 * 128, 256);
-    g.off_pairs = align_up(g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes, 256); // gen: whole waves
+    // the checked copy of a `_v_dev` call's block table + the bitmap of block numbers its check uses (redux_table.hpp)
+    g.off_table = align_up(g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes, 256); // gen: whole waves
+    g.off_seen  = g.off_table + align_up(g.nblocks * sizeof(redux_block), 256);
+    g.off_pairs = g.off_seen + align_up(table_seen_words(g.nblocks) * 4, 256);
     // a grid that leaves most SIMDs idle: the model by 64 lanes per block, the chain by one.  One block of any length --
     // redux_compress, the literal redux::compress -- is such a grid.  The pairs are rows of pair_width lanes (64, or the
     // number of blocks when there are fewer and they are large), block_size + slack rows per group of 64 blocks.
@@ -476,7 +480,7 @@ uint64_t redux_encode_workspace_bytes(const redux_params *p, uint64_t in_len, ui
 // d_table != null: the block table of redux_encode_blocks_v_dev (tbl_blocks entries; in_len = bytes of d_in)
 static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size,
                              const redux_block *d_table, uint64_t tbl_blocks, bool tbl_aligned16, void *d_block_status,
-                             void *d_workspace, uint64_t workspace_bytes, void *stream)
+                             void *d_workspace, uint64_t workspace_bytes, void *stream, uint64_t nblocks_real = 0)
 {
     int st = check_params(p);
     if (st != REDUX_OK)
@@ -497,6 +501,23 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
     hipStream_t s  = (hipStream_t)stream;
     uint8_t    *ws = (uint8_t *)d_workspace;
 
+    if (d_table) { // caller data: the kernels read a checked copy (redux_table.hpp)
+        TableCheckArgs ta;
+        ta.in         = d_table;
+        ta.out        = (redux_block *)(ws + g.off_table);
+        ta.nentries   = tbl_blocks;
+        ta.nblocks    = nblocks_real;
+        ta.bytes      = in_len;
+        ta.block_size = block_size;
+        ta.aligned16  = tbl_aligned16 ? 1u : 0u;
+        ta.seen       = (uint32_t *)(ws + g.off_seen);
+        ta.sizes      = (uint32_t *)(ws + g.off_sizes);
+        ta.status     = (int32_t *)d_block_status;
+        const uint64_t n0 = std::max(nblocks_real, table_seen_words(nblocks_real));
+        k_table_prepare<<<(uint32_t)((n0 + 255) / 256), 256, 0, s>>>(ta);
+        k_table_check<<<(uint32_t)((tbl_blocks + 255) / 256), 256, 0, s>>>(ta);
+        d_table = ta.out;
+    }
     HIP_TRY(hipMemsetAsync(ws + g.off_mode, 0, 256 + kClaimWords * 4, s)); // linear slots unless the pair kernel runs (below); empty role book
     if (g.gen) {
         GenEncArgs ga;
@@ -689,12 +710,22 @@ int redux_encode_blocks_v_dev(const redux_params *p, const void *d_in, uint64_t 
 {
     if (!d_table || nblocks == 0 || nentries < nblocks)
         return REDUX_INVALID_INPUT;
+    if (nentries > 0xFFFFFFF0ull || nblocks > 0xFFFFFFF0ull || !d_block_status || !d_workspace)
+        return REDUX_INVALID_INPUT;
     int st = encode_slots_impl(p, d_in, in_bytes, block_size, (const redux_block *)d_table, nentries,
-                               (flags & REDUX_V_ALIGNED16) != 0, d_block_status, d_workspace, workspace_bytes, stream);
+                               (flags & REDUX_V_ALIGNED16) != 0, d_block_status, d_workspace, workspace_bytes, stream, nblocks);
     if (st != REDUX_OK)
         return st;
-    return compact_with(geometry(p, nentries * (uint64_t)block_size, block_size), d_out, out_cap, d_out_offsets, d_block_status,
-                        d_summary, d_workspace, workspace_bytes, stream, (const redux_block *)d_table, nblocks);
+    // (from here on the table is its checked copy in the workspace)
+    const Geometry g = geometry(p, nentries * (uint64_t)block_size, block_size);
+    st = compact_with(g, d_out, out_cap, d_out_offsets, d_block_status, d_summary, d_workspace, workspace_bytes, stream,
+                      (const redux_block *)((uint8_t *)d_workspace + g.off_table), nblocks);
+    if (st != REDUX_OK)
+        return st;
+    k_table_verdict<<<1, 1, 0, (hipStream_t)stream>>>((const uint32_t *)((uint8_t *)d_workspace + g.off_seen) + table_seen_words(nblocks) - 1,
+                                                      (int32_t *)d_summary);
+    HIP_TRY(hipGetLastError());
+    return REDUX_OK;
 }
 
 uint64_t redux_block_count_v(const uint64_t *in_len, uint64_t ninputs, uint32_t block_size)
@@ -801,7 +832,8 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
                (gen_decode_cells(p, block_size) && gen_decode_in_workspace(p, nblocks) ? (nblocks + 63) / 64 * 64 * gen_decode_tree_bytes(p) : 0);
     if (g.any)
         return (nblocks ? nblocks : 1) * g.tree_bytes;
-    return align_up((uint64_t)g.rc_n * 8, 256);
+    // the reciprocal table, then room for the checked copy of a block table and its bitmap (redux_table.hpp)
+    return align_up((uint64_t)g.rc_n * 8, 256) + align_up(nblocks * sizeof(redux_block), 256) + align_up(table_seen_words(nblocks) * 4, 256);
 }
 
 // d_in_used (optional, u64[nblocks]): bytes of each stream the reader fetched; only
@@ -891,6 +923,26 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         return REDUX_OK;
     }
     k_fill_rc<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)d_workspace, g.rc_n);
+    const uint32_t *table_failed = nullptr;
+    if (d_table) { // caller data: the kernels read a checked copy (redux_table.hpp)
+        uint8_t *wt = (uint8_t *)d_workspace + align_up((uint64_t)g.rc_n * 8, 256);
+        TableCheckArgs ta;
+        ta.in         = d_table;
+        ta.out        = (redux_block *)wt;
+        ta.nentries   = nblocks;
+        ta.nblocks    = nblocks_real;
+        ta.bytes      = out_cap;
+        ta.block_size = block_size;
+        ta.aligned16  = tbl_aligned16 ? 1u : 0u;
+        ta.seen       = (uint32_t *)(wt + align_up(nblocks * sizeof(redux_block), 256));
+        ta.sizes      = (uint32_t *)d_out_sizes;
+        ta.status     = (int32_t *)d_block_status;
+        const uint64_t n0 = std::max(nblocks_real, table_seen_words(nblocks_real));
+        k_table_prepare<<<(uint32_t)((n0 + 255) / 256), 256, 0, s>>>(ta);
+        k_table_check<<<(uint32_t)((nblocks + 255) / 256), 256, 0, s>>>(ta);
+        d_table      = ta.out;
+        table_failed = ta.seen + table_seen_words(nblocks_real) - 1;
+    }
     DecArgs a;
     a.in         = (const uint8_t *)d_in;
     a.in_offsets = (const uint64_t *)d_in_offsets;
@@ -925,6 +977,8 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     }
     if (d_summary) // (with a block table nblocks counts its entries: statuses are per block)
         k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, d_table ? nblocks_real : nblocks, (int32_t *)d_summary);
+    if (table_failed)
+        k_table_verdict<<<1, 1, 0, s>>>(table_failed, (int32_t *)d_summary);
     HIP_TRY(hipGetLastError());
     return REDUX_OK;
 }
@@ -970,7 +1024,7 @@ int redux_decode_blocks_v_dev(const redux_params *p, const void *d_in, const voi
                               uint64_t out_bytes, void *d_out_sizes, void *d_block_status, void *d_summary, void *d_workspace,
                               uint64_t workspace_bytes, void *stream)
 {
-    if (!d_table || nblocks == 0 || nentries < nblocks || !d_out)
+    if (!d_table || nblocks == 0 || nentries < nblocks || !d_out || nentries > 0xFFFFFFF0ull)
         return REDUX_INVALID_INPUT;
     return decode_blocks_dev_impl(p, d_in, d_in_offsets, nentries, block_size, d_out, out_bytes, d_out_sizes, d_block_status,
                                   d_summary, d_workspace, workspace_bytes, stream, nullptr, (const redux_block *)d_table,

@@ -142,6 +142,11 @@ inline std::vector<std::uint8_t> decompress_blocks(const Blocks &streams, std::u
 {
     const redux_params cp = p.c_abi();
     check(redux_device_supports(&cp));
+    if (streams.offsets.empty() || streams.offsets.back() > streams.data.size())
+        throw Error::from_status(REDUX_INVALID_INPUT); // (the C call reads data[offsets[b] .. offsets[b + 1]) from caller memory)
+    for (std::size_t i = 1; i < streams.offsets.size(); i++)
+        if (streams.offsets[i] < streams.offsets[i - 1])
+            throw Error::from_status(REDUX_INVALID_INPUT);
     const std::uint64_t        nb = streams.offsets.size() - 1;
     std::vector<std::uint8_t>  out(nb * (std::uint64_t)block_size);
     std::vector<std::uint32_t> sz(nb);
@@ -191,6 +196,12 @@ inline std::vector<std::vector<std::uint8_t>> decompress_blocks_v(const Blocks &
     if (block_size == 0 || lengths.empty() || streams.offsets.empty() ||
         redux_block_count_v(lengths.data(), lengths.size(), block_size) + 1 != streams.offsets.size())
         throw Error::from_status(REDUX_INVALID_INPUT);
+    // the C call copies data[offsets.front() .. offsets.back()) from caller memory: inside `data`, in order
+    if (streams.offsets.front() != 0 || streams.offsets.back() > streams.data.size())
+        throw Error::from_status(REDUX_INVALID_INPUT);
+    for (std::size_t i = 1; i < streams.offsets.size(); i++)
+        if (streams.offsets[i] < streams.offsets[i - 1])
+            throw Error::from_status(REDUX_INVALID_INPUT);
     std::vector<std::uint64_t> off(lengths.size(), 0);
     for (std::size_t i = 1; i < lengths.size(); i++)
         off[i] = off[i - 1] + lengths[i - 1];

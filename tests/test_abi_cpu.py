@@ -212,3 +212,19 @@ def test_host_chunk_plan_deals_whole_waves_round_robin():
     L = _lib.lib()
     assert L.redux_host_chunk_plan(0, 4096, 1, 0, C.byref(C.c_uint64()), C.byref(C.c_uint64())) == _lib.INVALID_INPUT
     assert L.redux_host_chunk_plan(10, 4096, 17, 0, C.byref(C.c_uint64()), C.byref(C.c_uint64())) == _lib.INVALID_INPUT
+
+
+def test_decode_wrappers_reject_offsets_outside_the_streams():
+    """The host calls copy streams[offsets[b] .. offsets[b + 1]) out of caller memory: the mirrors refuse an offsets table that
+    runs past the bytes they were given, or backwards, before anything is read (no GPU involved)."""
+    streams = np.zeros(100, dtype=np.uint8)
+    with pytest.raises(api.InvalidInput):
+        api.decompress_blocks(streams, [0, 50, 101], 4096)
+    with pytest.raises(api.InvalidInput):
+        api.decompress_blocks(streams, [0, 60, 50], 4096)
+    with pytest.raises(api.InvalidInput):
+        api.decompress_blocks_v(streams, [0, 50, 101], [4096, 10], 4096)
+    with pytest.raises(api.InvalidInput):
+        api.decompress_blocks_v(streams, [1, 50, 100], [4096, 10], 4096)
+    with pytest.raises(api.InvalidInput):
+        api.decompress_blocks_v(streams, [0, 70, 60], [4096, 10], 4096)

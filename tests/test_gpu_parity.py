@@ -1082,7 +1082,7 @@ def test_batch_call_equals_per_input_calls_on_ragged_inputs(rx):
 
 def test_block_table_v_orders_whole_blocks_first(rx):
     tab = rx.block_table_v([0, 1000, 5000], [10, 2 * 4096 + 3, 4096], 4096)
-    live = tab[tab["index"] != api.BLOCK_IDLE] if "api" in globals() else tab[tab["index"] != 0xFFFFFFFF]
+    live = tab[tab["index"] != rx.BLOCK_IDLE]
     assert [int(e["index"]) for e in live] == [1, 2, 4, 0, 3]         # whole blocks in block order, then tails, longest first
     assert [int(e["length"]) for e in live] == [4096, 4096, 4096, 10, 3]
     assert [int(e["offset"]) for e in live] == [1000, 1000 + 4096, 5000, 0, 1000 + 8192]
@@ -1360,3 +1360,130 @@ def test_wave_decoder_on_damaged_large_blocks(rx, params):
         assert int(sizes[b]) == len(want), (b, len(stream), int(sizes[b]), len(want))
         assert dec[b * cap: b * cap + len(want)].tobytes() == want, (b, len(stream))
     assert {0, 1, 4} <= seen
+
+
+def test_hostile_block_tables_are_rejected_on_the_device(rx):
+    """The `_v_dev` calls take their block table from device memory: caller data.  Five hostile tables each way -- an index past
+    nblocks, a length above block_size, an offset + length past the buffer (once by overflow of the sum), a duplicated index, an
+    offset that breaks the REDUX_V_ALIGNED16 promise -- come back with InvalidInput (2) in the summary, the blocks of the VALID
+    entries coded exactly as without the hostile one, and guard bands around every buffer untouched (the reference's surface never
+    writes out of bounds: bitio/mod.rs:148-198 returns Err)."""
+    import ctypes as C
+    import torch
+    from redux_amd import _lib
+    L = _lib.lib()
+    BS, W = 4096, (8, 30, 32)
+    cp = _lib.Params(*W)
+    rng = np.random.default_rng(99)
+    nb = 70
+    data = (rng.integers(0, 256, nb * BS, dtype=np.uint8) >> 3)
+    good = np.zeros(128, dtype=rx.BLOCK_DTYPE)
+    good["index"] = rx.BLOCK_IDLE
+    for b in range(nb):
+        good[b] = (b * BS, BS, b)
+    G = 4096  # guard bytes on either side of every buffer
+    strm = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def guarded(nbytes, dtype=torch.uint8):
+        raw = torch.full((nbytes + 2 * G,), 0xAB, dtype=torch.uint8, device="cuda")
+        return raw, raw[G: G + nbytes]
+
+    def guards_ok(raw, nbytes):
+        return bool((raw[:G] == 0xAB).all()) and bool((raw[G + nbytes:] == 0xAB).all())
+
+    def encode(tab, flags=1):
+        ne = len(tab)
+        wsb = L.redux_encode_workspace_bytes(C.byref(cp), ne * BS, BS)
+        cap = nb * L.redux_encode_slot_bytes(C.byref(cp), BS)
+        r_in, d_in = guarded(nb * BS)
+        d_in.copy_(torch.from_numpy(data))
+        r_ws, ws = guarded(wsb)
+        r_out, d_out = guarded(cap)
+        r_off, d_off = guarded((nb + 1) * 8)
+        r_st, d_st = guarded(nb * 4)
+        r_sum, d_sum = guarded(8)
+        d_sum.zero_()
+        d_tab = torch.from_numpy(tab.view(np.uint8).copy()).cuda()
+        assert ws.data_ptr() % 256 == 0
+        r = L.redux_encode_blocks_v_dev(C.byref(cp), C.c_void_p(d_in.data_ptr()), nb * BS, C.c_void_p(d_tab.data_ptr()), ne, nb, BS, flags,
+                                        C.c_void_p(d_out.data_ptr()), cap, C.c_void_p(d_off.data_ptr()), C.c_void_p(d_st.data_ptr()),
+                                        C.c_void_p(d_sum.data_ptr()), C.c_void_p(ws.data_ptr()), wsb, strm)
+        torch.cuda.synchronize()
+        assert r == 0
+        for raw, n in ((r_in, nb * BS), (r_ws, wsb), (r_out, cap), (r_off, (nb + 1) * 8), (r_st, nb * 4), (r_sum, 8)):
+            assert guards_ok(raw, n)
+        assert bool((torch.from_numpy(tab.view(np.uint8).copy()).cuda() == d_tab).all())  # the caller's table is not written
+        offs = d_off.view(torch.int64).cpu().numpy()
+        return d_sum.view(torch.int32).tolist(), d_st.view(torch.int32).cpu().numpy(), offs, d_out.cpu().numpy()
+
+    summary, st, offs, out = encode(good)
+    assert summary == [0, 0] and not st.any()
+    want = [out[int(offs[b]): int(offs[b + 1])].tobytes() for b in range(nb)]
+    assert want[3] == ox.compress(data[3 * BS: 4 * BS].tobytes(), W)[0]
+
+    def hostile(kind):
+        t = good.copy()
+        hit = 5  # the entry that is damaged (block 5), or the slot a bad entry is added in
+        if kind == "index":
+            t[100] = (0, BS, nb + 1000)
+        elif kind == "length":
+            t[hit]["length"] = BS + 1
+        elif kind == "offset":
+            t[hit]["offset"] = nb * BS - 100
+        elif kind == "overflow":
+            t[hit]["offset"] = (1 << 64) - 16
+        elif kind == "duplicate":
+            t[100] = (7 * BS, BS, 7)
+        elif kind == "misaligned":
+            t[hit]["offset"] = 5 * BS + 8
+        return t
+
+    for kind in ("index", "length", "offset", "overflow", "duplicate", "misaligned"):
+        summary, st, offs, out = encode(hostile(kind))
+        assert summary[0] == 2 and summary[1] >= 1, (kind, summary)
+        lost = {5} if kind in ("length", "offset", "overflow", "misaligned") else set()
+        for b in range(nb):
+            got = out[int(offs[b]): int(offs[b + 1])].tobytes()
+            if b in lost:
+                assert st[b] == 2 and got == b""
+            else:
+                assert st[b] == 0 and got == want[b], (kind, b)
+
+    # ---- decode: entry.offset / entry.length say where a block's output goes
+    streams = np.frombuffer(b"".join(want), dtype=np.uint8)
+    soffs = np.zeros(nb + 1, dtype=np.int64)
+    soffs[1:] = np.cumsum([len(x) for x in want])
+
+    def decode(tab, flags=1):
+        ne = len(tab)
+        wsb = L.redux_decode_workspace_bytes(C.byref(cp), ne, BS)
+        r_in, d_in = guarded(len(streams))
+        d_in.copy_(torch.from_numpy(streams.copy()))
+        r_ws, ws = guarded(wsb)
+        r_out, d_out = guarded(nb * BS)
+        r_sz, d_sz = guarded(nb * 4)
+        r_st, d_st = guarded(nb * 4)
+        r_sum, d_sum = guarded(8)
+        d_sum.zero_()
+        d_offs = torch.from_numpy(soffs).cuda()
+        d_tab = torch.from_numpy(tab.view(np.uint8).copy()).cuda()
+        r = L.redux_decode_blocks_v_dev(C.byref(cp), C.c_void_p(d_in.data_ptr()), C.c_void_p(d_offs.data_ptr()), C.c_void_p(d_tab.data_ptr()), ne, nb,
+                                        BS, flags, C.c_void_p(d_out.data_ptr()), nb * BS, C.c_void_p(d_sz.data_ptr()), C.c_void_p(d_st.data_ptr()),
+                                        C.c_void_p(d_sum.data_ptr()), C.c_void_p(ws.data_ptr()), wsb, strm)
+        torch.cuda.synchronize()
+        assert r == 0
+        for raw, n in ((r_in, len(streams)), (r_ws, wsb), (r_out, nb * BS), (r_sz, nb * 4), (r_st, nb * 4), (r_sum, 8)):
+            assert guards_ok(raw, n)
+        return d_sum.view(torch.int32).tolist(), d_st.view(torch.int32).cpu().numpy(), d_sz.view(torch.int32).cpu().numpy(), d_out.cpu().numpy()
+
+    summary, st, sz, dec = decode(good)
+    assert summary == [0, 0] and (dec == data).all()
+    for kind in ("index", "length", "offset", "overflow", "duplicate", "misaligned"):
+        summary, st, sz, dec = decode(hostile(kind))
+        assert summary[0] == 2 and summary[1] >= 1, (kind, summary)
+        lost = {5} if kind in ("length", "offset", "overflow", "misaligned") else set()
+        for b in range(nb):
+            if b in lost:
+                assert st[b] == 2 and sz[b] == 0
+            else:
+                assert st[b] == 0 and sz[b] == BS and (dec[b * BS:(b + 1) * BS] == data[b * BS:(b + 1) * BS]).all(), (kind, b)

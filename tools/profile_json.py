@@ -32,6 +32,15 @@ def counters(root, sub):
     return out
 
 
+def read_bytes(c):
+    """Bytes the L2 read over the fabric.  With the request counters by size class at hand they are exact (32/64/128-byte
+    requests); otherwise FETCH_SIZE doubled, the guide's gfx950 correction for wide coalesced reads (FETCH_SIZE prices the
+    128-byte requests through TCC_BUBBLE, which gfx950 leaves at zero, so they are tallied at 64 bytes)."""
+    if all(k in c for k in ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")):
+        return int(32 * c["TCC_EA0_RDREQ_32B_sum"] + 64 * c["TCC_EA0_RDREQ_64B_sum"] + 128 * c["TCC_EA0_RDREQ_128B_sum"]), "size classes"
+    return int(2 * c["FETCH_SIZE"] * 1024), "2 x FETCH_SIZE"
+
+
 def merge(path, key, entry, header):
     doc = json.load(open(path)) if os.path.exists(path) else dict(header)
     doc.update({k: v for k, v in header.items() if k not in doc})
@@ -51,7 +60,7 @@ def main():
     ap.add_argument("--encode")
     ap.add_argument("--decode")
     ap.add_argument("--workload", default="iid")
-    ap.add_argument("--round", default="3")
+    ap.add_argument("--round", default="4")
     args = ap.parse_args()
     from redux_amd import _lib
     src = _lib.lib().redux_source_hash().decode()
@@ -59,12 +68,15 @@ def main():
     if args.encode:
         c = counters(args.encode, "k_encode_pair")
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            merge(os.path.join(ROOT, "profiles", "traffic.json"), ("workload", "blocks"), {
+            rb, how = read_bytes(c)
+            merge(os.path.join(ROOT, "profiles", "traffic.json"), ("workload", "blocks", "kernel"), {
                 "workload": args.workload, "blocks": BLOCKS, "kernel": "k_encode_pair<false, true>", "source_hash": src,
                 "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
-                "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
-                "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE (separate passes) of `python3 bench.py --steps 2 "
-                          f"--warmup 1 --no-cpu-baseline --no-decode --workload {args.workload}`, round {args.round}",
+                "rdreq": {k: c[k] for k in c if k.startswith("TCC_EA0_RDREQ")},
+                "read_bytes": rb, "read_bytes_from": how,
+                "hbm_bytes_per_launch": int(2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024),
+                "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE / --pmc TCC_EA0_RDREQ_* (separate passes) of `python3 bench.py "
+                          f"--steps 2 --warmup 1 --no-cpu-baseline --no-decode --workload {args.workload}`, round {args.round}",
             }, {"correction": "gfx950: FETCH_SIZE counts 128-B line requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM). WRITE_SIZE exact."})
         if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
             valu = c["SQ_INSTS_VALU"] / (groups * SYMBOLS)
@@ -80,6 +92,20 @@ def main():
                         "tools/prof_decode.sh -> tools/profile_json.py); bench.py copies the entry of the loaded library's source hash"})
     if args.decode:
         c = counters(args.decode, "k_decode_lock")
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            rb, how = read_bytes(c)
+            merge(os.path.join(ROOT, "profiles", "traffic.json"), ("workload", "blocks", "kernel"), {
+                "workload": args.workload, "blocks": BLOCKS, "kernel": "k_decode_lock<true>", "source_hash": src,
+                "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"],
+                "rdreq": {k: c[k] for k in c if k.startswith("TCC_EA0_RDREQ")},
+                "read_bytes": rb, "read_bytes_from": how,
+                # per-lane 16-byte loads are not the guide's calibrated case (wide coalesced reads), so the read side is priced by
+                # request size class; tools/ubench/fetchsize.hip (profiles/r04_ubench/fetchsize_gfx950.txt): EVERY read request of
+                # this chip's L2 is a 128-byte one, coalesced or per lane, so this equals 2 x FETCH_SIZE here too
+                "hbm_bytes_per_launch": int(rb + c["WRITE_SIZE"] * 1024),
+                "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE / --pmc TCC_EA0_RDREQ_* (separate passes, tools/prof_decode.sh) of "
+                          f"`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --decode --workload {args.workload}`, round {args.round}",
+            }, {})
         if "SQ_INSTS_VALU" in c and "SQ_WAVE_CYCLES" in c:
             valu = c["SQ_INSTS_VALU"] / (groups * SYMBOLS)
             cyc = 4 * c["SQ_WAVE_CYCLES"] / groups / SYMBOLS
