@@ -23,7 +23,7 @@
  *     stream), never allocate, never synchronise and keep no pointer after they return.
  *   - Thread-safe.  The `_dev` calls and the geometry helpers keep no state at all.  The
  *     host-pointer calls share ONE lazily created, mutex-guarded context per device (chunk slots
- *     in HBM, pinned staging, streams; grown on demand, never shrunk, freed by
+ *     in HBM, pinned staging, streams; grown on demand, buffers above 1 GiB given back when their call ends, freed by
  *     redux_host_release()): calls from several host threads are safe; two that use the same
  *     context run one after the other, two on different devices run concurrently.
  *   - The `_dev` calls launch on HIP's CURRENT device; every pointer must belong to it.
@@ -174,6 +174,10 @@ int  redux_host_set_chunk_bytes(uint64_t min_bytes, uint64_t max_bytes);
  * harness checks that it does not move in the steady state. */
 int      redux_host_release(void);
 uint64_t redux_host_allocations(void);
+/* Device memory the contexts hold right now, in bytes.  A context keeps what the chunk pipeline can ask for and gives
+ * back slot buffers above 1 GiB when the call that needed them ends (one block of hundreds of MiB, a generous decode
+ * capacity); the decoders' workspace does not grow with the capacity at all (a bounded reciprocal table). */
+uint64_t redux_host_resident_bytes(void);
 /* Diagnostic: the timeline of the last host-pointer call on the current device, four doubles per
  * chunk (seconds since the call began): staging begins, device work enqueued, kernels done, results
  * in caller memory.  Copies up to cap doubles, returns how many there are. */

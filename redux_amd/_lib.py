@@ -51,6 +51,7 @@ SIGNATURES = {
     "redux_host_chunk_plan": (C.c_int, [_U64, _U32, _U32, C.c_int, C.POINTER(_U64), C.POINTER(_U64)]),
     "redux_host_set_chunk_bytes": (C.c_int, [_U64, _U64]),
     "redux_host_allocations": (_U64, []),
+    "redux_host_resident_bytes": (_U64, []),
     "redux_host_trace": (_U64, [C.POINTER(C.c_double), _U64]),
     "redux_encode_blocks_dev": (C.c_int, [_PP, _V, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),
     "redux_decode_blocks_dev": (C.c_int, [_PP, _V, _V, _U64, _U32, _V, _U64, _V, _V, _V, _V, _U64, _V]),

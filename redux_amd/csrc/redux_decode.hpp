@@ -39,7 +39,24 @@ struct DecArgs {
     // written at out + offset and may hold `length` <= block_size bytes; index 0xFFFFFFFF: an idle lane.  nblocks counts
     // table entries then.
     const redux_block *table;
+    // Entries of the reciprocal table at rc (k_fill_rc: rc[i] for 257 + i).  It covers min(block capacity, freeze point)
+    // updates, but at most kDecRcWindow: a decoder that may run past that (k_decode, k_decode_wave: blocks of any
+    // length, redux_decompress with a generous capacity) computes the reciprocals beyond it itself (rc_lookup), so the
+    // workspace is bounded whatever the capacity.
+    uint32_t rc_n;
 };
+constexpr uint32_t kDecRcWindow = 1u << 20;
+
+// The reciprocal the coder multiplies with at update number `nup` (wave-uniform), count = count0 + nup: from the table
+// while it lasts, otherwise computed as k_fill_rc computes an entry -- the correctly rounded 1 / count, biased up 4 ulp
+// (scale_div's proof needs exactly that value) -- ~15 instructions of a step that has ~165.
+__device__ __forceinline__ double rc_lookup(rc_ptr rc, uint32_t rc_n, uint32_t nup, uint32_t count0)
+{
+    if (nup < rc_n) // (scalar branch)
+        return rc[nup];
+    const double r = 1.0 / (double)(count0 + nup);
+    return __longlong_as_double(__double_as_longlong(r) + 4);
+}
 
 // BitReader (bitio/mod.rs:78-120) as a 64-bit look-ahead register: the `cnt` not yet
 // consumed bits sit in the TOP of `bits`; refills are whole aligned dwords, big-endian
@@ -145,7 +162,7 @@ __global__ void __launch_bounds__(64) k_decode(DecArgs a)
         if (__builtin_amdgcn_readfirstlane(__ballot(!done) == 0))
             break;
         const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
-        const double   rc  = rcp[nup];
+        const double   rc  = rc_lookup(rcp, a.rc_n, nup, 257u);
         const uint32_t c   = 257u + nup;
         if (!done) {
             // value = ((pending - low + 1) * count - 1) / range      (codec.rs:129-131)

@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
         for (;; p++) {
             const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
             const double   rc  = rc_next;
-            rc_next            = rcp[p + 1 < a.nfreeze ? p + 1 : a.nfreeze]; // (the table has 32 entries of slack)
+            rc_next            = rc_lookup(rcp, a.rc_n, p + 1 < a.nfreeze ? p + 1 : a.nfreeze, 257u); // (computed past the table's window)
             const uint32_t c   = 257u + nup;
             // value = ((pending - low + 1) * count - 1) / range      (codec.rs:129-131)
             const uint32_t R1 = (high - low) >> sh;

@@ -822,6 +822,13 @@ int redux_compress(const redux_params *p, const uint8_t *in, uint64_t in_len, ui
     return rc;
 }
 
+// entries of the decoders' reciprocal table: what the block capacity (or the freeze point) asks for, but at most
+// kDecRcWindow + slack -- a decoder of longer blocks computes the rest itself (rc_lookup, redux_decode.hpp)
+static uint32_t dec_rc_entries(const Geometry &g)
+{
+    return (g.gen || g.rc_n <= kDecRcWindow + 32) ? g.rc_n : kDecRcWindow + 32;
+}
+
 uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, uint32_t block_size)
 {
     if (check_params(p) != REDUX_OK || block_size == 0)
@@ -833,7 +840,7 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
     if (g.any)
         return (nblocks ? nblocks : 1) * g.tree_bytes;
     // the reciprocal table, then room for the checked copy of a block table and its bitmap (redux_table.hpp)
-    return align_up((uint64_t)g.rc_n * 8, 256) + align_up(nblocks * sizeof(redux_block), 256) + align_up(table_seen_words(nblocks) * 4, 256);
+    return align_up((uint64_t)dec_rc_entries(g) * 8, 256) + align_up(nblocks * sizeof(redux_block), 256) + align_up(table_seen_words(nblocks) * 4, 256);
 }
 
 // d_in_used (optional, u64[nblocks]): bytes of each stream the reader fetched; only
@@ -922,10 +929,11 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         HIP_TRY(hipGetLastError());
         return REDUX_OK;
     }
-    k_fill_rc<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)d_workspace, g.rc_n);
+    const uint32_t rc_n = dec_rc_entries(g);
+    k_fill_rc<<<(rc_n + 255) / 256, 256, 0, s>>>((double *)d_workspace, rc_n);
     const uint32_t *table_failed = nullptr;
     if (d_table) { // caller data: the kernels read a checked copy (redux_table.hpp)
-        uint8_t *wt = (uint8_t *)d_workspace + align_up((uint64_t)g.rc_n * 8, 256);
+        uint8_t *wt = (uint8_t *)d_workspace + align_up((uint64_t)rc_n * 8, 256);
         TableCheckArgs ta;
         ta.in         = d_table;
         ta.out        = (redux_block *)wt;
@@ -961,6 +969,7 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         a.aligned4 = (tbl_aligned16 && (((uintptr_t)d_out) & 15) == 0) ? 2 : 0;
     a.in_used    = (uint64_t *)d_in_used;
     a.table      = d_table;
+    a.rc_n       = rc_n - 32; // (the last 32 entries are slack for the lock-step decoder's look-ahead)
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
     switch (pick_decode_kernel(g, p, nblocks)) {
     case DecKernel::Wave: k_decode_wave<false><<<(uint32_t)nblocks, 64, 0, s>>>(a); break;
@@ -1296,6 +1305,20 @@ uint64_t redux_host_allocations(void)
     for (host::Ctx &c : host::g_ctx) {
         std::lock_guard<std::mutex> l(c.mu);
         n += c.allocs;
+    }
+    return n;
+}
+
+uint64_t redux_host_resident_bytes(void)
+{
+    uint64_t n = 0;
+    for (host::Ctx &c : host::g_ctx) {
+        std::lock_guard<std::mutex> l(c.mu);
+        if (!c.ready)
+            continue;
+        for (host::Slot &s : c.slot)
+            for (const host::Buf *b : {&s.d_in, &s.d_ws, &s.d_out, &s.d_off, &s.d_sz, &s.d_st, &s.d_sum, &s.d_used, &s.d_tab})
+                n += b->cap;
     }
     return n;
 }

@@ -139,6 +139,9 @@ struct Slot {          // one chunk in flight
 
 struct Ctx {
     std::mutex  mu;
+    // Both only ever written with mu held: `want` by the call that has just locked the context (the device it is to run on),
+    // `device` by ctx_init_locked / ctx_teardown_locked (the device the streams, events and buffers below were created on).
+    int         want = -1;
     int         device = -1;
     bool        ready = false;
     hipStream_t stream[kStreams] = {};
@@ -200,19 +203,27 @@ static int grow_pinned(Ctx &c, Buf &b, size_t need)
 
 // the context of HIP's current device; its streams, events and staging ring are created by the first call that
 // holds its mutex (ctx_init_locked) and torn down by redux_host_release under the same mutex
-static int ctx_of_current_device(Ctx **out)
+static int ctx_of_current_device(Ctx **out, int *dev_out)
 {
     int dev = 0;
     HOST_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16)
         return REDUX_UNSUPPORTED;
-    g_ctx[dev].device = dev;
-    *out              = &g_ctx[dev];
+    *out     = &g_ctx[dev];
+    *dev_out = dev;
     return REDUX_OK;
 }
 
-static int ctx_init_locked(Ctx &c) // c.mu is held
+static void ctx_teardown_locked(Ctx &c);
+
+// c.mu is held and c.want says which device the call runs on.  A context that was built for another device -- the fleet
+// was reconfigured, or fleet entry i and default-mode device d share g_ctx[] -- is torn down first: its streams, events,
+// HBM and pinned buffers belong to the device they were created on.
+static int ctx_init_locked(Ctx &c)
 {
+    if (c.ready && c.device != c.want)
+        ctx_teardown_locked(c); // (leaves HIP's current device at c.device: set again below)
+    HOST_TRY(hipSetDevice(c.want));
     if (c.ready)
         return REDUX_OK;
     int pri_lo = 0, pri_hi = 0; // numerically: lo = least urgent, hi = most urgent
@@ -227,12 +238,57 @@ static int ctx_init_locked(Ctx &c) // c.mu is held
         HOST_TRY(hipEventCreateWithFlags(&c.piece_free[i], hipEventDisableTiming));
         c.allocs++;
     }
-    c.ready = true;
+    c.device = c.want;
+    c.ready  = true;
     return REDUX_OK;
 }
 
 static void free_buf_dev(Buf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 static void free_buf_pin(Buf &b) { if (b.p) (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+
+// frees everything the context holds on the device it was built for (c.mu is held)
+static void ctx_teardown_locked(Ctx &c)
+{
+    if (!c.ready)
+        return;
+    (void)hipSetDevice(c.device);
+    for (int i = 0; i < kStreams; i++) // (a call in flight holds c.mu, so these are idle: belt and braces)
+        if (c.stream[i]) (void)hipStreamSynchronize(c.stream[i]);
+    for (Slot &s : c.slot) {
+        free_buf_dev(s.d_in); free_buf_dev(s.d_ws); free_buf_dev(s.d_out); free_buf_dev(s.d_off); free_buf_dev(s.d_sz);
+        free_buf_dev(s.d_st); free_buf_dev(s.d_sum); free_buf_dev(s.d_used); free_buf_dev(s.d_tab);
+        free_buf_pin(s.h_off); free_buf_pin(s.h_sz); free_buf_pin(s.h_st); free_buf_pin(s.h_sum); free_buf_pin(s.h_used);
+        free_buf_pin(s.h_tab);
+        if (s.done) (void)hipEventDestroy(s.done);
+        s.done = nullptr;
+    }
+    for (int i = 0; i < kPieces; i++) {
+        if (c.piece[i]) (void)hipHostFree(c.piece[i]);
+        if (c.piece_free[i]) (void)hipEventDestroy(c.piece_free[i]);
+        c.piece[i] = nullptr; c.piece_free[i] = nullptr;
+    }
+    for (int i = 0; i < kStreams; i++) {
+        if (c.stream[i]) (void)hipStreamDestroy(c.stream[i]);
+        c.stream[i] = nullptr;
+    }
+    if (c.drain) (void)hipStreamDestroy(c.drain);
+    c.drain = nullptr;
+    c.ready = false;
+}
+
+// A call on an unusually large shape (one block of hundreds of MiB, a generous decode capacity) leaves slot buffers behind
+// that no ordinary call needs: the context keeps what the chunk pipeline itself can ask for (256 MiB of payload + workspace)
+// and gives back anything above kTrimBytes when such a call ends.
+constexpr size_t kTrimBytes = 1ull << 30;
+static void ctx_trim_locked(Ctx &c)
+{
+    if (!c.ready)
+        return;
+    for (Slot &s : c.slot)
+        for (Buf *b : {&s.d_in, &s.d_ws, &s.d_out})
+            if (b->cap > kTrimBytes)
+                free_buf_dev(*b);
+}
 
 static int ctx_release_all()
 {
@@ -244,31 +300,7 @@ static int ctx_release_all()
     } restore{caller_dev};
     for (Ctx &c : g_ctx) {
         std::lock_guard<std::mutex> lc(c.mu); // waits for a call in flight on that device
-        if (!c.ready)
-            continue;
-        (void)hipSetDevice(c.device);
-        for (int i = 0; i < kStreams; i++) // (a call in flight holds c.mu, so these are idle: belt and braces)
-            if (c.stream[i]) (void)hipStreamSynchronize(c.stream[i]);
-        for (Slot &s : c.slot) {
-            free_buf_dev(s.d_in); free_buf_dev(s.d_ws); free_buf_dev(s.d_out); free_buf_dev(s.d_off); free_buf_dev(s.d_sz);
-            free_buf_dev(s.d_st); free_buf_dev(s.d_sum); free_buf_dev(s.d_used); free_buf_dev(s.d_tab);
-            free_buf_pin(s.h_off); free_buf_pin(s.h_sz); free_buf_pin(s.h_st); free_buf_pin(s.h_sum); free_buf_pin(s.h_used);
-            free_buf_pin(s.h_tab);
-            if (s.done) (void)hipEventDestroy(s.done);
-            s.done = nullptr;
-        }
-        for (int i = 0; i < kPieces; i++) {
-            if (c.piece[i]) (void)hipHostFree(c.piece[i]);
-            if (c.piece_free[i]) (void)hipEventDestroy(c.piece_free[i]);
-            c.piece[i] = nullptr; c.piece_free[i] = nullptr;
-        }
-        for (int i = 0; i < kStreams; i++) {
-            if (c.stream[i]) (void)hipStreamDestroy(c.stream[i]);
-            c.stream[i] = nullptr;
-        }
-        if (c.drain) (void)hipStreamDestroy(c.drain);
-        c.drain = nullptr;
-        c.ready = false;
+        ctx_teardown_locked(c);
     }
     return REDUX_OK;
 }
@@ -319,24 +351,46 @@ static std::mutex       g_fleet_mu;
 static std::vector<int> g_fleet;                                    // empty: current device only
 static std::atomic<uint64_t> g_chunk_min{0}, g_chunk_max{0};        // test hook (redux_host_set_chunk_bytes): 0 = the defaults
 
-static int contexts_for_call(std::vector<Ctx *> &out)
+// Which contexts a call runs on, and the device each is to run on.  Nothing of a context is touched here: the caller locks
+// every context's mutex (always in this order) and only then records the device in it (take_contexts).
+static int contexts_for_call(std::vector<Ctx *> &out, std::vector<int> &want)
 {
     std::lock_guard<std::mutex> l(g_fleet_mu);
     if (g_fleet.empty()) {
-        Ctx *cp = nullptr;
-        int  rc = ctx_of_current_device(&cp);
+        Ctx *cp  = nullptr;
+        int  dev = 0;
+        int  rc  = ctx_of_current_device(&cp, &dev);
         if (rc != REDUX_OK)
             return rc;
         out.push_back(cp);
+        want.push_back(dev);
         return REDUX_OK;
     }
     for (size_t i = 0; i < g_fleet.size(); i++) {
-        g_ctx[i].device = g_fleet[i];
         out.push_back(&g_ctx[i]);
+        want.push_back(g_fleet[i]);
     }
     return REDUX_OK;
 }
 
+// contexts_for_call + their mutexes, taken in context order (two calls cannot deadlock); each context then knows its device
+static int take_contexts(std::vector<Ctx *> &ctx, std::vector<std::unique_lock<std::mutex>> &locks)
+{
+    std::vector<int> want;
+    int rc = contexts_for_call(ctx, want);
+    if (rc != REDUX_OK)
+        return rc;
+    for (size_t i = 0; i < ctx.size(); i++) {
+        locks.emplace_back(ctx[i]->mu);
+        ctx[i]->want = want[i];
+    }
+    return REDUX_OK;
+}
+
+// The fleet changes under g_fleet_mu, held across the assignment AND the release of the old contexts: a call that asks for
+// its contexts meanwhile waits, then sees the new fleet.  (A call that already holds contexts of the old fleet finishes
+// first -- the release waits for its mutexes -- and whatever it leaves built for an old device is rebuilt by the next
+// call that finds the device changed: ctx_init_locked.)
 static int set_devices(const int32_t *ids, uint32_t n)
 {
     if (n > 16 || (n && !ids))
@@ -347,9 +401,9 @@ static int set_devices(const int32_t *ids, uint32_t n)
     for (uint32_t i = 0; i < n; i++)
         if (ids[i] < 0 || ids[i] >= count)
             return REDUX_INVALID_INPUT;
-    ctx_release_all(); // contexts are bound to a device when they are built: start from none
     std::lock_guard<std::mutex> l(g_fleet_mu);
     g_fleet.assign(ids, ids + n);
+    ctx_release_all(); // contexts are bound to a device when they are built: start from none
     return REDUX_OK;
 }
 
@@ -415,9 +469,7 @@ struct EncCall {
 // the chunks first, first + stride, ... of the call on context c (the calling thread of the call holds c.mu)
 static void encode_on_ctx(Ctx &c, const EncCall &E, Job &J, uint64_t first, uint64_t stride)
 {
-    if (hipSetDevice(c.device) != hipSuccess)
-        return J.fail(REDUX_IO_ERROR);
-    int rc = ctx_init_locked(c);
+    int rc = ctx_init_locked(c); // (makes c.want HIP's current device on this thread)
     if (rc != REDUX_OK)
         return J.fail(rc);
     const uint64_t mine = first < E.nchunks ? (E.nchunks - first + stride - 1) / stride : 0; // chunks of this context
@@ -567,12 +619,10 @@ static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_l
                          uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
 {
     std::vector<Ctx *> ctx;
-    int rc = contexts_for_call(ctx);
+    std::vector<std::unique_lock<std::mutex>> locks;
+    int rc = take_contexts(ctx, locks);
     if (rc != REDUX_OK)
         return rc;
-    std::vector<std::unique_lock<std::mutex>> locks; // (always taken in context order: two calls cannot deadlock)
-    for (Ctx *c : ctx)
-        locks.emplace_back(c->mu);
     int caller_dev = -1;
     (void)hipGetDevice(&caller_dev);
 
@@ -598,6 +648,11 @@ static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_l
     encode_on_ctx(*ctx[0], E, J, 0, nctx);
     for (auto &t : th)
         t.join();
+    for (Ctx *c : ctx) {
+        if (c->ready)
+            (void)hipSetDevice(c->device);
+        ctx_trim_locked(*c);
+    }
     if (caller_dev >= 0)
         (void)hipSetDevice(caller_dev);
     if (J.error != REDUX_OK)
@@ -628,9 +683,7 @@ struct DecCall {
 
 static void decode_on_ctx(Ctx &c, const DecCall &D, Job &J, uint64_t first, uint64_t stride)
 {
-    if (hipSetDevice(c.device) != hipSuccess)
-        return J.fail(REDUX_IO_ERROR);
-    int rc = ctx_init_locked(c);
+    int rc = ctx_init_locked(c); // (makes c.want HIP's current device on this thread)
     if (rc != REDUX_OK)
         return J.fail(rc);
     const uint64_t mine   = first < D.nchunks ? (D.nchunks - first + stride - 1) / stride : 0;
@@ -769,12 +822,10 @@ static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_
 {
     (void)out_cap;
     std::vector<Ctx *> ctx;
-    int rc = contexts_for_call(ctx);
+    std::vector<std::unique_lock<std::mutex>> locks;
+    int rc = take_contexts(ctx, locks);
     if (rc != REDUX_OK)
         return rc;
-    std::vector<std::unique_lock<std::mutex>> locks;
-    for (Ctx *c : ctx)
-        locks.emplace_back(c->mu);
     int caller_dev = -1;
     (void)hipGetDevice(&caller_dev);
 
@@ -800,6 +851,11 @@ static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_
     decode_on_ctx(*ctx[0], D, J, 0, nctx);
     for (auto &t : th)
         t.join();
+    for (Ctx *c : ctx) {
+        if (c->ready)
+            (void)hipSetDevice(c->device);
+        ctx_trim_locked(*c);
+    }
     if (caller_dev >= 0)
         (void)hipSetDevice(caller_dev);
     if (J.error != REDUX_OK)
@@ -837,12 +893,12 @@ static int encode_blocks_v(const redux_params *p, const uint8_t *in, const uint6
                            uint32_t block_size, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
 {
     std::vector<Ctx *> ctx;
-    int rc = contexts_for_call(ctx);
+    std::vector<std::unique_lock<std::mutex>> locks;
+    int rc = take_contexts(ctx, locks);
     if (rc != REDUX_OK)
         return rc;
     Ctx &c = *ctx[0]; // (a fleet's first context: a batch is one launch)
-    std::lock_guard<std::mutex> lock(c.mu);
-    DeviceScope scope(c.device);
+    DeviceScope scope(c.want);
     if ((rc = ctx_init_locked(c)) != REDUX_OK)
         return rc;
     Slot       &s  = c.slot[0];
@@ -911,12 +967,12 @@ static int decode_blocks_v(const redux_params *p, const uint8_t *in, const uint6
                            DecodeDevCall dev_call)
 {
     std::vector<Ctx *> ctx;
-    int rc = contexts_for_call(ctx);
+    std::vector<std::unique_lock<std::mutex>> locks;
+    int rc = take_contexts(ctx, locks);
     if (rc != REDUX_OK)
         return rc;
     Ctx &c = *ctx[0];
-    std::lock_guard<std::mutex> lock(c.mu);
-    DeviceScope scope(c.device);
+    DeviceScope scope(c.want);
     if ((rc = ctx_init_locked(c)) != REDUX_OK)
         return rc;
     Slot       &s  = c.slot[0];

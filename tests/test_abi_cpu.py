@@ -228,3 +228,13 @@ def test_decode_wrappers_reject_offsets_outside_the_streams():
         api.decompress_blocks_v(streams, [1, 50, 100], [4096, 10], 4096)
     with pytest.raises(api.InvalidInput):
         api.decompress_blocks_v(streams, [0, 70, 60], [4096, 10], 4096)
+
+
+def test_decode_workspace_does_not_grow_with_the_capacity():
+    """redux::decompress writes to an unbounded sink with O(1) state (lib.rs:113-120): a decode capacity of 1 GiB asks for a
+    bounded workspace (a reciprocal table of 2^20 entries + slack, not one entry per byte of capacity)."""
+    L = _lib.lib()
+    p = _lib.Params(8, 30, 32)
+    assert L.redux_decode_workspace_bytes(C.byref(p), 1, 1 << 30) <= (64 << 20)
+    assert L.redux_decode_workspace_bytes(C.byref(p), 1, 0xFFFFFF00) <= (64 << 20)
+    assert L.redux_decode_workspace_bytes(C.byref(p), 65536, 65536) <= (4 << 20)

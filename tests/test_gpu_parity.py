@@ -887,6 +887,7 @@ def test_decompress_without_max_output_grows_its_buffer(rx):
     """redux::decompress writes to an unbounded io::Write (src/lib.rs:113).  3 MiB of one byte
     value compresses to a few hundred bytes; the default capacity guess (64 x input, at least
     1 MiB) is too small for it and must grow instead of failing."""
+    from redux_amd import _lib
     data = b"\0" * (3 << 20)
     model = rx.AdaptiveTreeModel.new(rx.Parameters.new(8, 30, 32))
     c = io.BytesIO()
@@ -894,11 +895,36 @@ def test_decompress_without_max_output_grows_its_buffer(rx):
     assert bi == len(data) and bo < 4096
     want, _ = ox.compress(data, (8, 30, 32))
     assert c.getvalue() == want
+    assert _lib.lib().redux_host_release() == 0   # (what the encoder and earlier tests left in the contexts does not count below)
     d = io.BytesIO()
     assert rx.decompress(io.BytesIO(c.getvalue()), d, model) == (bo, len(data))
     assert d.getvalue() == data
     with pytest.raises(rx.OutputTooSmall):   # an explicit limit is still a limit
         rx.decompress(io.BytesIO(c.getvalue()), io.BytesIO(), model, max_output=1 << 20)
+    # the decoder's state is O(1) in the reference (lib.rs:113-120): a generous capacity must not cost memory.  The
+    # reciprocal table is a window of 2^20 entries (the 3 MiB above ran two thirds of their steps past it, on computed
+    # reciprocals), and what the contexts hold afterwards is the chunk pipeline's own, not gigabytes
+    assert _lib.lib().redux_host_resident_bytes() < (256 << 20)
+    d = io.BytesIO()
+    assert rx.decompress(io.BytesIO(c.getvalue()), d, model, max_output=1 << 30) == (bo, len(data)) and d.getvalue() == data
+    assert _lib.lib().redux_host_resident_bytes() < (1 << 30) + (256 << 20)
+
+
+def test_long_blocks_decode_past_the_reciprocal_window(rx):
+    """Blocks of more than 2^20 symbols: the decoders that take them (k_decode_wave in small launches, k_decode otherwise)
+    read their reciprocals from a table of 2^20 entries and compute the later ones (rc_lookup): the same values, so the
+    same bytes.  1.5 MiB blocks of text and noise, streams from the encoder checked against the oracle first."""
+    rng = np.random.default_rng(31)
+    text = open(os.path.join(GOLDEN, "corpora", "large", "bible.txt"), "rb").read()
+    bs = (3 << 19) + 40
+    data = text[: bs + 1000] + bytes((rng.integers(0, 256, 2 * bs - 1000 - 77, dtype=np.uint8) >> 1).tolist())
+    for w in ((8, 30, 32), (8, 22, 24)):
+        out, offs, st = rx.compress_blocks(data, bs, w)
+        assert not st.any() and len(offs) == 4
+        for b in range(3):
+            assert out[int(offs[b]): int(offs[b + 1])].tobytes() == ox.compress(data[b * bs:(b + 1) * bs], w)[0], (w, b)
+        dec, sizes, dst = rx.decompress_blocks(out, offs, bs, w)
+        assert not dst.any() and b"".join(dec[b * bs: b * bs + int(sizes[b])].tobytes() for b in range(3)) == data
 
 
 def test_kernel_names_follow_the_dispatch(rx):
