@@ -84,13 +84,111 @@ def self_launch(n, argv, run=None):
     return (run or subprocess.call)(cmd, env=env)
 
 
+def file_workload(args, rx, torch, dist, rank, world, dev):
+    """BASELINE.json configs[3] (SURVEY 8(d) cfg 4: "latency-bound; report time, not roofline"): one file, cut into 64 KiB
+    blocks, contiguous block ranges scattered from rank 0 over RCCL (exact byte counts, grouped send / recv), coded by every
+    rank with the HIP kernels, compressed ranges gathered back to rank 0; then the same way back through the decoder.  A step
+    is one such round trip; the line reports the mean time of each phase over the timed steps (max over ranks of each step's
+    wall time for `value`), the streams are checked against tests/golden/blocks.json and the decoded file against the input."""
+    import hashlib
+    from redux_amd import dist as rd
+    path = args.workload[5:] if args.workload.startswith("file:") else ""
+    path = path or os.path.join(ROOT, "tests", "golden", "corpora", "large", "bible.txt")
+    if world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29641")
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+    data, raw = None, b""
+    if rank == 0:
+        raw = open(path, "rb").read()
+        data = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev) if raw else torch.empty(0, dtype=torch.uint8, device=dev)
+    enc_local, dec_local = rd.hip_encode_local(PARAMS), rd.hip_decode_local(PARAMS)
+    phases = {k: 0.0 for k in ("scatter_ms", "encode_ms", "gather_ms", "decode_scatter_ms", "decode_ms", "decode_gather_ms")}
+    enc_wall = dec_wall = 0.0
+    dense = offs = back = None
+    for it in range(args.warmup + args.steps):
+        timed = it >= args.warmup
+        dist.barrier()
+        torch.cuda.synchronize()
+        m1, m2 = [], []
+        t0 = time.perf_counter()
+        dense, offs = rd.encode_file_sharded(data, BLOCK, enc_local, dev, marks=m1)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        back = rd.decode_file_sharded(dense, offs, BLOCK, dec_local, dev, marks=m2)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if timed:
+            enc_wall += t1 - t0
+            dec_wall += t2 - t1
+            for k, (_, dt) in zip(("scatter_ms", "encode_ms", "gather_ms"), m1):
+                phases[k] += dt * 1e3
+            for k, (_, dt) in zip(("decode_scatter_ms", "decode_ms", "decode_gather_ms"), m2):
+                phases[k] += dt * 1e3
+    # max over ranks of the walls and of every phase (a phase lasts as long as its slowest rank)
+    t = torch.tensor([enc_wall, dec_wall] + [phases[k] for k in sorted(phases)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    vals = t.tolist()
+    enc_wall, dec_wall = vals[0], vals[1]
+    phases = {k: round(v / args.steps, 3) for k, v in zip(sorted(phases), vals[2:])}
+    if rank == 0:
+        n = len(raw)
+        nblocks = max(1, (n + BLOCK - 1) // BLOCK)
+        assert back.cpu().numpy().tobytes() == raw, "decode(encode(file)) != file"
+        o = offs.cpu().numpy()
+        d = dense.cpu().numpy()
+        golden = None
+        gpath = os.path.join(ROOT, "tests", "golden", "blocks.json")
+        key = os.path.relpath(os.path.abspath(path), os.path.join(ROOT, "tests", "golden", "corpora"))
+        if os.path.exists(gpath) and not key.startswith(".."):
+            gold = json.load(open(gpath)).get(key, {}).get("%d_%d_%d" % PARAMS)
+            if gold:
+                h64 = lambda b: hashlib.blake2b(b, digest_size=8).hexdigest()  # noqa: E731  (tests/golden/make_fixtures.py)
+                assert [int(x) for x in (o[1:] - o[:-1])] == gold["block_sizes"], "block sizes differ from tests/golden/blocks.json"
+                assert [h64(d[int(o[i]): int(o[i + 1])].tobytes()) for i in range(nblocks)] == gold["block_hashes"], \
+                    "streams differ from tests/golden/blocks.json"
+                golden = "every block's size and blake2b-64 equal tests/golden/blocks.json"
+        per = (nblocks + world - 1) // world
+        line = {
+            "metric": "encode MB/s (whole node), per-block bitstream bit-exact",
+            "value": round(n * args.steps / enc_wall / 1e6, 2) if enc_wall else None,
+            "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(enc_wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32", "data": "file",
+            "config": {"workload": f"file:{os.path.relpath(path, ROOT)} cut into 64 KiB blocks, contiguous block ranges scattered from rank 0, coded, "
+                                   "gathered (BASELINE.json configs[3]; SURVEY 8(d) cfg 4: time, not roofline)",
+                       "bytes": n, "block_size": BLOCK, "blocks": nblocks, "blocks_per_rank": per, "parameters": list(PARAMS),
+                       "parallelism": f"{world} rank(s); exchange: sizes first, then exact byte counts as grouped send/recv ("
+                                      + ("gloo, staged through host memory" if args.rehearse_on_one_gpu else "RCCL") + ")",
+                       "compressed_over_input": round(int(o[-1]) / n, 5) if n else None},
+            "phases": phases,
+            "decode_ms_per_step": round(dec_wall / args.steps * 1e3, 3),
+            "roundtrip_equal": True, "golden": golden,
+            "roofline": None, "cpu_baseline": None,
+            "note": ("latency-bound: one block's serial chain (~5 ms encode, ~21 ms decode per 64 KiB block) is the floor of a launch whatever "
+                     "the number of ranks; " + ("rehearsal of the multi-rank code path on one GPU, not a scaling measurement"
+                                                if args.rehearse_on_one_gpu else ("unmeasured at N > 1 on this pool's one-GPU boxes" if world == 1 else ""))),
+        }
+        print(json.dumps(line))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=10)  # the chip's clocks settle only after ~0.2 s of load
     ap.add_argument("--blocks", type=int, default=65536, help="blocks per GPU (default: the config's 65,536)")
-    ap.add_argument("--workload", choices=["iid", "zipf"], default="iid")
+    ap.add_argument("--workload", default="iid",
+                    help="iid (default, BASELINE configs[1]) | zipf (configs[4] shape) | file[:<path>] -- BASELINE configs[3]: the root scatters "
+                         "a file's 64 KiB blocks over the ranks, every rank codes its range, the root gathers and decodes back the same way "
+                         "(default file: tests/golden/corpora/large/bible.txt); prints its own line (time per phase, not a roofline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode", action="store_true", help="(default) also time the decode kernel after the timed encode steps")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode measurement / round-trip check")
@@ -127,6 +225,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     import redux_amd as rx
+
+    if args.workload == "file" or args.workload.startswith("file:"):
+        return file_workload(args, rx, torch, dist, rank, world, dev)
+    if args.workload not in ("iid", "zipf"):
+        print(f"bench.py: unknown --workload {args.workload}", file=sys.stderr)
+        sys.exit(2)
 
     nblocks = args.blocks
     n = nblocks * BLOCK
@@ -305,6 +409,7 @@ def main():
         assert torch.equal(s_out[:stotal], enc.out[:stotal]), "small-grid kernels and the full-grid kernel differ on the same blocks"
         line["small_launch"] = {"blocks": sb, "encode_ms": round(e0.elapsed_time(e1), 3), "decode_ms": round(e1.elapsed_time(e2), 3),
                                 "encode_kernel": _lib.lib().redux_encode_kernel_name(C.byref(cp), C.c_void_p(s_in.data_ptr()), sn, BLOCK).decode().split(" (")[0],
+                                "decode_kernel": _lib.lib().redux_decode_kernel_name_n(C.byref(cp), None, BLOCK, sb).decode().split(" (")[0],
                                 "equal_to_full_grid_streams": True}
 
     if world == 1 and not args.no_cpu_baseline:

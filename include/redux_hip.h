@@ -278,6 +278,11 @@ const char *redux_source_hash(void);
  * roofline.kernel) instead of assuming the fast path was taken. */
 const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size);
 const char *redux_decode_kernel_name(const redux_params *p, const void *d_out, uint32_t block_size);
+/* The decoder also depends on the SIZE of the launch (blocks the lock-step decoder does not take run one per wave in
+ * launches of at most 1024 blocks, k_decode_wave; 11- and 12-bit symbols keep their bottom tree cells in LDS on small grids):
+ * nblocks = blocks (or table entries) of the launch; 0 = a grid that fills the chip, which is what
+ * redux_decode_kernel_name answers for. */
+const char *redux_decode_kernel_name_n(const redux_params *p, const void *d_out, uint32_t block_size, uint64_t nblocks);
 
 /* Diagnostic, used by the parity tests only: *max_err = max over the integers x in [lo, hi] of
  * |v_rcp_f64(x) * x - 1| evaluated on the device.  The decoder's code-value division

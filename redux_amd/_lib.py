@@ -7,7 +7,10 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libredux_hip.so")
+# The product library, in-tree.  REDUX_LIB names another build to load instead: how the A/B tools (tools/run_variants.sh,
+# tools/small_grid.py ...) time a variant without ever overwriting the product library (an interrupted run used to leave
+# a foreign library in its place that needs_build() would not replace).
+LIB_PATH = os.environ.get("REDUX_LIB") or os.path.join(HERE, "libredux_hip.so")
 
 OK, EOF, INVALID_INPUT, IO_ERROR, OUTPUT_TOO_SMALL, UNSUPPORTED = 0, 1, 2, 3, 4, 5
 
@@ -27,6 +30,7 @@ SIGNATURES = {
     "redux_source_hash": (C.c_char_p, []),
     "redux_encode_kernel_name": (C.c_char_p, [_PP, _V, _U64, _U32]),
     "redux_decode_kernel_name": (C.c_char_p, [_PP, _V, _U32]),
+    "redux_decode_kernel_name_n": (C.c_char_p, [_PP, _V, _U32, _U64]),
     "redux_debug_rcp_check": (C.c_int, [_U64, _U64, C.POINTER(C.c_double)]),
     "redux_debug_role_book": (C.c_int, [_PP, _U64, _U32, C.POINTER(_U64), C.POINTER(_U64)]),
     "redux_params_check": (C.c_int, [_U32, _U32, _U32]),

@@ -412,11 +412,16 @@ const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, ui
 
 const char *redux_decode_kernel_name(const redux_params *p, const void *d_out, uint32_t block_size)
 {
+    return redux_decode_kernel_name_n(p, d_out, block_size, 0);
+}
+
+const char *redux_decode_kernel_name_n(const redux_params *p, const void *d_out, uint32_t block_size, uint64_t nblocks)
+{
     if (check_params(p) != REDUX_OK || block_size == 0)
         return "";
     (void)d_out; // every decoder takes any alignment (it only picks the store width inside the kernel)
     const Geometry g = geometry(p, block_size, block_size);
-    switch (pick_decode_kernel(g, p, 0, block_size)) {
+    switch (pick_decode_kernel(g, p, nblocks, block_size)) {
     case DecKernel::LockCb32: return "k_decode_lock<true> (u16 tree, one wave per 64 blocks, code_bits 32)";
     case DecKernel::Lock: return "k_decode_lock<false> (u16 tree, one wave per 64 blocks)";
     case DecKernel::GenericU16: return "k_decode<true, false> (u16 tree, per-lane control flow)";

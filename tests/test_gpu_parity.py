@@ -680,6 +680,15 @@ def test_sharded_driver_on_gpu_world1(rx):
         assert [h64(d[int(o[i]): int(o[i + 1])]) for i in range(len(o) - 1)] == gold["block_hashes"]
         back = rd.decode_file_sharded(dense, offs, BLOCK, rd.hip_decode_local((8, 30, 32)), "cuda:0")
         assert back.cpu().numpy().tobytes() == raw
+        # the local coders hand out VIEWS of their cached buffers, valid until their next call (redux_amd/dist.py): a result that
+        # is to outlive the next call is cloned, and calling again with the first input gives the first result again
+        f = rd.hip_encode_local((8, 30, 32))
+        a, b = data[: 5 * BLOCK + 123], data[7 * BLOCK: 9 * BLOCK]
+        o1, f1 = f(a, BLOCK)
+        o1, f1 = o1.clone(), f1.clone()
+        f(b, BLOCK)
+        o3, f3 = f(a, BLOCK)
+        assert torch.equal(o1, o3) and torch.equal(f1, f3[: f1.numel()])
     finally:
         dist.destroy_process_group()
 
@@ -977,6 +986,14 @@ def test_bench_self_launch_two_ranks_on_one_gpu(rx):
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and "rehearsal" in line
+    # BASELINE configs[3] the same way: bible.txt scattered over two ranks (sizes first, then exact byte counts; gloo stages the
+    # transfers through host memory), coded with the HIP kernels, gathered, decoded back, streams against tests/golden/blocks.json
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "file", "--steps", "2", "--warmup", "1",
+                        "--rehearse-on-one-gpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["blocks"] == 62 and line["config"]["blocks_per_rank"] == 31
+    assert line["roundtrip_equal"] and line["golden"] and all(line["phases"][k] >= 0 for k in ("scatter_ms", "encode_ms", "gather_ms", "decode_ms"))
 
 
 def test_host_abi_pipeline_many_chunks(rx):

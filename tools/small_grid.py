@@ -52,11 +52,6 @@ if __name__ == "__main__":
     if not libs:
         measure()
         sys.exit(0)
-    keep = open(LIB, "rb").read()
-    try:
-        for lib in libs:
-            open(LIB, "wb").write(open(lib, "rb").read())
-            print("==", lib, flush=True)
-            subprocess.run([sys.executable, os.path.abspath(__file__)], check=False, timeout=300)
-    finally:
-        open(LIB, "wb").write(keep)
+    for lib in libs:  # (each build in a child process that loads it through REDUX_LIB: the in-tree library is never overwritten)
+        print("==", lib, flush=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__)], check=False, timeout=300, env=dict(os.environ, REDUX_LIB=os.path.abspath(lib)))
