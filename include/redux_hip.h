@@ -145,8 +145,14 @@ int redux_decode_blocks_v(const redux_params *p, const uint8_t *in, const uint64
 
 /* Whole-stream drop-ins for redux::compress / redux::decompress (src/lib.rs:102,113): the
  * input is ONE block of any length, so the stream equals the reference's for the same bytes.
- * One coder = one GPU lane: correct but serial; the block API is the accelerated path.
- * bytes_in / bytes_out are the (u64,u64) the reference returns. */
+ * One coder = one chain of dependent symbols: correct but serial (the model is computed by a wave, the
+ * interval chain by one lane; the decoder is one wave per stream); the block API is the accelerated path.
+ * bytes_in / bytes_out are the (u64,u64) the reference returns.
+ * LIMIT: one block is at most 0xFFFFFF00 bytes (symbol index, byte offsets and the consumed-bit count of a lane
+ * are 32-bit in the kernels): redux_compress returns REDUX_UNSUPPORTED for a longer input, redux_decompress
+ * clamps out_cap to it (a stream that decodes to more comes back REDUX_OUTPUT_TOO_SMALL).  The reference takes
+ * any io::Read (src/lib.rs:102); a caller with more than 4 GiB in ONE stream has no parallelism to gain here
+ * (~10 MB/s against ~14 MB/s for one CPU thread) and should use the block API or the CPU. */
 int redux_compress(const redux_params *p, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
                    uint64_t *bytes_in, uint64_t *bytes_out);
 int redux_decompress(const redux_params *p, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
@@ -158,7 +164,8 @@ int redux_decompress(const redux_params *p, const uint8_t *in, uint64_t in_len, 
  * device ids[i] -- chunk k goes to context k mod n -- each with its own streams, HBM slots and
  * pinned staging, each fed over its own PCIe link by its own host threads; the data starts and ends
  * in host memory, so the devices exchange nothing (no collective).  An id may appear more than once
- * (two contexts on one device: what the one-GPU test box exercises).  The `_v` calls use context 0.
+ * (two contexts on one device: what the one-GPU test box exercises).  The `_v` calls deal their GROUPS of inputs
+ * (512 MiB of payload each) the same way, group k on context k mod n.
  * Existing contexts are released by the call.  Returns INVALID_INPUT for an id that is not a device.
  * redux_host_chunk_plan: the chunking such a call uses for nblocks blocks on ncontexts contexts
  * (whole waves of 64 blocks per chunk); host arithmetic only.

@@ -867,10 +867,11 @@ static int decode_blocks(const redux_params *p, const uint8_t *in, const uint64_
 // many independent inputs in one call (redux_encode_blocks_v / redux_decode_blocks_v)
 //
 // Consecutive inputs are packed into GROUPS of at most kVGroupBytes; a group is staged into HBM with every input at a
-// 16-byte boundary (so that the fast kernels apply), coded by ONE launch over its block table and copied back.  Groups
-// run one after the other on the context's first slot: the point of these calls is many small inputs -- the reference's
-// corpus harness, 36 files of 4 KB - 4 MB -- where what counts is that all blocks share a launch, not the overlap of
-// transfers with kernels that the chunk pipeline above gives gigabyte inputs.
+// 16-byte boundary (so that the fast kernels apply), coded by ONE launch over its block table and copied back.  The point
+// of these calls is many small inputs -- the reference's corpus harness, 36 files of 4 KB - 4 MB, is one group -- where
+// what counts is that all blocks share a launch.  A batch of several groups is dealt over the fleet (redux_host_set_devices):
+// group k runs on context k mod n, each context on its first slot and its own thread; the encoder's dense output keeps
+// block order through a ledger of group sizes.
 // ================================================================================================
 constexpr uint64_t kVGroupBytes = 512ull << 20;
 
@@ -889,172 +890,308 @@ struct DeviceScope { // makes `dev` HIP's current device for a scope and puts th
     }
 };
 
-static int encode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len, uint64_t ninputs,
-                           uint32_t block_size, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
+// One group of consecutive inputs = one launch.  first_block = number of its first block; nb its blocks.
+struct VGroup {
+    uint64_t i0, i1, first_block, nb;
+};
+
+// inputs [0, ninputs) -> groups of at most kVGroupBytes of (16-byte padded) payload each
+static std::vector<VGroup> v_groups(const uint64_t *len, uint64_t ninputs, uint32_t block_size)
+{
+    std::vector<VGroup> g;
+    uint64_t            blk = 0;
+    const uint64_t      cap = g_chunk_max.load() ? g_chunk_max.load() : kVGroupBytes; // (redux_host_set_chunk_bytes: a harness drives many groups through a small batch)
+    for (uint64_t i0 = 0; i0 < ninputs;) {
+        uint64_t i1 = i0, pos = 0;
+        do {
+            pos += (len[i1] + 15) & ~15ull;
+            i1++;
+        } while (i1 < ninputs && pos + len[i1] <= cap);
+        const uint64_t nb = redux_block_count_v(len + i0, i1 - i0, block_size);
+        g.push_back({i0, i1, blk, nb});
+        blk += nb;
+        i0 = i1;
+    }
+    return g;
+}
+
+// What the contexts of one `_v` call share: the groups are dealt round-robin (group k on context k mod n, each context
+// taking its groups in order), and -- encode only -- a group's place in the dense output is known once every earlier
+// group's size is.
+struct VJob {
+    std::mutex              m;
+    std::condition_variable cv;
+    std::vector<uint64_t>   total;
+    std::vector<char>       known;
+    std::vector<int>        bad;   // first non-OK block status of each group
+    int                     error = REDUX_OK;
+    bool                    abort = false;
+
+    explicit VJob(size_t n) : total(n, 0), known(n, 0), bad(n, REDUX_OK) {}
+    void fail(int rc)
+    {
+        std::lock_guard<std::mutex> l(m);
+        if (error == REDUX_OK)
+            error = rc;
+        abort = true;
+        cv.notify_all();
+    }
+    void publish(size_t g, uint64_t t)
+    {
+        std::lock_guard<std::mutex> l(m);
+        total[g] = t;
+        known[g] = 1;
+        cv.notify_all();
+    }
+    // bytes of all groups before g, once they are all known; false if the call was aborted meanwhile
+    bool base_of(size_t g, uint64_t &base)
+    {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] {
+            if (abort)
+                return true;
+            for (size_t h = 0; h < g; h++)
+                if (!known[h])
+                    return false;
+            return true;
+        });
+        if (abort)
+            return false;
+        base = 0;
+        for (size_t h = 0; h < g; h++)
+            base += total[h];
+        return true;
+    }
+};
+
+struct EncVCall {
+    const redux_params *p;
+    const uint8_t      *in;
+    const uint64_t     *in_off, *in_len;
+    uint32_t            block_size;
+    uint8_t            *out;
+    uint64_t            out_cap;
+    uint64_t           *out_offsets;
+    int32_t            *block_status;
+};
+
+static int encode_v_group(Ctx &c, const EncVCall &E, const VGroup &G, size_t gi, VJob &J, CopyPool &pool, uint64_t &piece_no)
+{
+    int         rc;
+    Slot       &s  = c.slot[0];
+    hipStream_t st = c.stream[0];
+    std::vector<uint64_t> doff;
+    uint64_t              pos = 0;
+    for (uint64_t i = G.i0; i < G.i1; i++) {
+        doff.push_back(pos);
+        pos += (E.in_len[i] + 15) & ~15ull;
+    }
+    if (pos > 0xFFFFFFFFull) // (one input of 4 GiB or more: lane offsets are 32-bit; redux_encode_blocks takes it)
+        return REDUX_UNSUPPORTED;
+    const uint64_t nb = G.nb;
+    const uint64_t ne = redux_block_table_v(doff.data(), E.in_len + G.i0, G.i1 - G.i0, E.block_size, nullptr); // entries: blocks + idle lanes
+    std::vector<redux_block> tbl(ne);
+    redux_block_table_v(doff.data(), E.in_len + G.i0, G.i1 - G.i0, E.block_size, tbl.data());
+    const uint64_t ws_bytes = redux_encode_workspace_bytes(E.p, ne * (uint64_t)E.block_size, E.block_size);
+    const uint64_t bound    = nb * redux_encode_slot_bytes(E.p, E.block_size);
+    if ((rc = grow_dev(c, s.d_in, pos + 16)) || (rc = grow_dev(c, s.d_ws, ws_bytes + 256)) || (rc = grow_dev(c, s.d_out, bound + 16)) ||
+        (rc = grow_dev(c, s.d_off, (nb + 1) * 8)) || (rc = grow_dev(c, s.d_st, nb * 4)) || (rc = grow_dev(c, s.d_sum, 8)) ||
+        (rc = grow_dev(c, s.d_tab, ne * sizeof(redux_block))) || (rc = grow_pinned(c, s.h_off, (nb + 1) * 8)) ||
+        (rc = grow_pinned(c, s.h_st, nb * 4)) || (rc = grow_pinned(c, s.h_sum, 8)) || (rc = grow_pinned(c, s.h_tab, ne * sizeof(redux_block))))
+        return rc;
+    memcpy(s.h_tab.p, tbl.data(), ne * sizeof(redux_block));
+    HOST_TRY(hipMemcpyAsync(s.d_tab.p, s.h_tab.p, ne * sizeof(redux_block), hipMemcpyHostToDevice, st));
+    for (uint64_t k = 0; k < G.i1 - G.i0; k++)
+        if (E.in_len[G.i0 + k] &&
+            (rc = stage_h2d(c, pool, piece_no, (uint8_t *)s.d_in.p + doff[k], E.in + E.in_off[G.i0 + k], E.in_len[G.i0 + k], st)))
+            return rc;
+    HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
+    uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
+    if ((rc = redux_encode_blocks_v_dev(E.p, s.d_in.p, pos, s.d_tab.p, ne, nb, E.block_size, REDUX_V_ALIGNED16, s.d_out.p, bound, s.d_off.p,
+                                        s.d_st.p, s.d_sum.p, ws, ws_bytes, st)))
+        return rc;
+    HOST_TRY(hipMemcpyAsync(s.h_off.p, s.d_off.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
+    HOST_TRY(hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st));
+    HOST_TRY(hipMemcpyAsync(s.h_sum.p, s.d_sum.p, 8, hipMemcpyDeviceToHost, st));
+    HOST_TRY(hipStreamSynchronize(st));
+    const uint64_t *ho    = (const uint64_t *)s.h_off.p;
+    const uint64_t  total = ho[nb];
+    J.publish(gi, total);
+    uint64_t out_base = 0;
+    if (!J.base_of(gi, out_base)) // (another group failed)
+        return REDUX_OK;
+    if (out_base + total > E.out_cap)
+        return REDUX_OUTPUT_TOO_SMALL;
+    if (total && (rc = drain_d2h(c, E.out + out_base, s.d_out.p, total)))
+        return rc;
+    for (uint64_t i = 0; i <= nb; i++) // (entry nb is also the next group's entry 0: the same value from either side)
+        E.out_offsets[G.first_block + i] = out_base + ho[i];
+    if (E.block_status)
+        memcpy(E.block_status + G.first_block, s.h_st.p, nb * 4);
+    J.bad[gi] = ((const int32_t *)s.h_sum.p)[0];
+    return REDUX_OK;
+}
+
+// runs fn(group index) for the groups first, first + stride, ... on context c (whose mutex the call holds)
+template <typename F>
+static void v_on_ctx(Ctx &c, size_t ngroups, size_t first, size_t stride, VJob &J, F &&fn)
+{
+    int rc = ctx_init_locked(c); // (makes c.want HIP's current device on this thread)
+    if (rc != REDUX_OK)
+        return J.fail(rc);
+    CopyPool pool(kCopyThreads - 1);
+    uint64_t piece_no = 0;
+    for (size_t g = first; g < ngroups; g += stride) {
+        {
+            std::lock_guard<std::mutex> l(J.m);
+            if (J.abort)
+                break;
+        }
+        if ((rc = fn(c, g, pool, piece_no)) != REDUX_OK)
+            return J.fail(rc);
+    }
+    (void)hipStreamSynchronize(c.stream[0]);
+}
+
+template <typename F>
+static int v_deal(size_t ngroups, VJob &J, F &&fn)
 {
     std::vector<Ctx *> ctx;
     std::vector<std::unique_lock<std::mutex>> locks;
     int rc = take_contexts(ctx, locks);
     if (rc != REDUX_OK)
         return rc;
-    Ctx &c = *ctx[0]; // (a fleet's first context: a batch is one launch)
-    DeviceScope scope(c.want);
-    if ((rc = ctx_init_locked(c)) != REDUX_OK)
-        return rc;
+    int caller_dev = -1;
+    (void)hipGetDevice(&caller_dev);
+    const size_t nctx = ctx.size() < ngroups ? ctx.size() : ngroups; // (the reference's corpus is one group: one context)
+    std::vector<std::thread> th;
+    for (size_t d = 1; d < nctx; d++)
+        th.emplace_back([&, d] { v_on_ctx(*ctx[d], ngroups, d, nctx, J, fn); });
+    v_on_ctx(*ctx[0], ngroups, 0, nctx, J, fn);
+    for (auto &t : th)
+        t.join();
+    for (Ctx *c : ctx) {
+        if (c->ready)
+            (void)hipSetDevice(c->device);
+        ctx_trim_locked(*c);
+    }
+    if (caller_dev >= 0)
+        (void)hipSetDevice(caller_dev);
+    if (J.error != REDUX_OK)
+        return J.error;
+    for (int b : J.bad) // the first group (in block order) with a non-OK block decides
+        if (b != REDUX_OK)
+            return b;
+    return REDUX_OK;
+}
+
+static int encode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_off, const uint64_t *in_len, uint64_t ninputs,
+                           uint32_t block_size, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, int32_t *block_status)
+{
+    const std::vector<VGroup> groups = v_groups(in_len, ninputs, block_size);
+    EncVCall E{p, in, in_off, in_len, block_size, out, out_cap, out_offsets, block_status};
+    VJob     J(groups.size());
+    return v_deal(groups.size(), J, [&](Ctx &c, size_t g, CopyPool &pool, uint64_t &piece_no) {
+        return encode_v_group(c, E, groups[g], g, J, pool, piece_no);
+    });
+}
+
+struct DecVCall {
+    const redux_params *p;
+    const uint8_t      *in;
+    const uint64_t     *in_offsets;
+    uint8_t            *out;
+    const uint64_t     *out_off, *out_len;
+    uint32_t            block_size;
+    uint32_t           *out_sizes;
+    int32_t            *block_status;
+    DecodeDevCall       dev_call;
+};
+
+static int decode_v_group(Ctx &c, const DecVCall &D, const VGroup &G, size_t gi, VJob &J, CopyPool &pool, uint64_t &piece_no)
+{
+    int         rc;
     Slot       &s  = c.slot[0];
     hipStream_t st = c.stream[0];
-    CopyPool    pool(kCopyThreads - 1);
-    uint64_t    piece_no = 0, blk_base = 0, out_base = 0;
-    int         first_bad = REDUX_OK;
-    std::vector<uint64_t>    doff;
-    std::vector<redux_block> tbl;
-    for (uint64_t i0 = 0; i0 < ninputs;) {
-        uint64_t i1 = i0, pos = 0;
-        doff.clear();
-        do {
-            doff.push_back(pos);
-            pos += (in_len[i1] + 15) & ~15ull;
-            i1++;
-        } while (i1 < ninputs && pos + in_len[i1] <= kVGroupBytes);
-        if (pos > 0xFFFFFFFFull) // (one input of 4 GiB or more: lane offsets are 32-bit; redux_encode_blocks takes it)
-            return REDUX_UNSUPPORTED;
-        const uint64_t nb = redux_block_count_v(in_len + i0, i1 - i0, block_size);
-        const uint64_t ne = redux_block_table_v(doff.data(), in_len + i0, i1 - i0, block_size, nullptr); // entries: blocks + idle lanes
-        tbl.resize(ne);
-        redux_block_table_v(doff.data(), in_len + i0, i1 - i0, block_size, tbl.data());
-        const uint64_t ws_bytes = redux_encode_workspace_bytes(p, ne * (uint64_t)block_size, block_size);
-        const uint64_t bound    = nb * redux_encode_slot_bytes(p, block_size);
-        if ((rc = grow_dev(c, s.d_in, pos + 16)) || (rc = grow_dev(c, s.d_ws, ws_bytes + 256)) || (rc = grow_dev(c, s.d_out, bound + 16)) ||
-            (rc = grow_dev(c, s.d_off, (nb + 1) * 8)) || (rc = grow_dev(c, s.d_st, nb * 4)) || (rc = grow_dev(c, s.d_sum, 8)) ||
-            (rc = grow_dev(c, s.d_tab, ne * sizeof(redux_block))) || (rc = grow_pinned(c, s.h_off, (nb + 1) * 8)) ||
-            (rc = grow_pinned(c, s.h_st, nb * 4)) || (rc = grow_pinned(c, s.h_sum, 8)) || (rc = grow_pinned(c, s.h_tab, ne * sizeof(redux_block))))
-            return rc;
-        memcpy(s.h_tab.p, tbl.data(), ne * sizeof(redux_block));
-        HOST_TRY(hipMemcpyAsync(s.d_tab.p, s.h_tab.p, ne * sizeof(redux_block), hipMemcpyHostToDevice, st));
-        for (uint64_t k = 0; k < i1 - i0; k++)
-            if (in_len[i0 + k] && (rc = stage_h2d(c, pool, piece_no, (uint8_t *)s.d_in.p + doff[k], in + in_off[i0 + k], in_len[i0 + k], st)))
-                return rc;
-        HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
-        uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
-        if ((rc = redux_encode_blocks_v_dev(p, s.d_in.p, pos, s.d_tab.p, ne, nb, block_size, REDUX_V_ALIGNED16, s.d_out.p, bound, s.d_off.p,
-                                            s.d_st.p, s.d_sum.p, ws, ws_bytes, st)))
-            return rc;
-        HOST_TRY(hipMemcpyAsync(s.h_off.p, s.d_off.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
-        HOST_TRY(hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st));
-        HOST_TRY(hipMemcpyAsync(s.h_sum.p, s.d_sum.p, 8, hipMemcpyDeviceToHost, st));
-        HOST_TRY(hipStreamSynchronize(st));
-        const uint64_t *ho    = (const uint64_t *)s.h_off.p;
-        const uint64_t  total = ho[nb];
-        if (out_base + total > out_cap)
-            return REDUX_OUTPUT_TOO_SMALL;
-        if (total && (rc = drain_d2h(c, out + out_base, s.d_out.p, total)))
-            return rc;
-        for (uint64_t i = 0; i <= nb; i++)
-            out_offsets[blk_base + i] = out_base + ho[i];
-        if (block_status)
-            memcpy(block_status + blk_base, s.h_st.p, nb * 4);
-        if (first_bad == REDUX_OK && ((const int32_t *)s.h_sum.p)[0] != REDUX_OK)
-            first_bad = ((const int32_t *)s.h_sum.p)[0];
-        blk_base += nb;
-        out_base += total;
-        i0 = i1;
+    std::vector<uint64_t> doff;
+    uint64_t              pos = 0;
+    for (uint64_t i = G.i0; i < G.i1; i++) {
+        doff.push_back(pos);
+        pos += (D.out_len[i] + 15) & ~15ull;
     }
-    return first_bad;
+    const uint64_t nb = G.nb, blk_base = G.first_block;
+    const uint64_t ne = redux_block_table_v(doff.data(), D.out_len + G.i0, G.i1 - G.i0, D.block_size, nullptr);
+    std::vector<redux_block> tbl(ne);
+    redux_block_table_v(doff.data(), D.out_len + G.i0, G.i1 - G.i0, D.block_size, tbl.data()); // offset = where the block goes, length = its room
+    const uint64_t sb0 = D.in_offsets[blk_base];
+    for (uint64_t i = 0; i < nb; i++)
+        if (D.in_offsets[blk_base + i + 1] < D.in_offsets[blk_base + i])
+            return REDUX_INVALID_INPUT;
+    const uint64_t len_in = D.in_offsets[blk_base + nb] - sb0;
+    if (len_in && !D.in)
+        return REDUX_INVALID_INPUT;
+    const uint64_t wsb = redux_decode_workspace_bytes(D.p, ne, D.block_size);
+    if ((rc = grow_dev(c, s.d_in, len_in + 32)) || (rc = grow_dev(c, s.d_ws, wsb + 256)) || (rc = grow_dev(c, s.d_out, pos + 16)) ||
+        (rc = grow_dev(c, s.d_off, (nb + 1) * 8)) || (rc = grow_dev(c, s.d_sz, nb * 4)) || (rc = grow_dev(c, s.d_st, nb * 4)) ||
+        (rc = grow_dev(c, s.d_sum, 8)) || (rc = grow_dev(c, s.d_tab, ne * sizeof(redux_block))) ||
+        (rc = grow_pinned(c, s.h_off, (nb + 1) * 8)) || (rc = grow_pinned(c, s.h_sz, nb * 4)) || (rc = grow_pinned(c, s.h_st, nb * 4)) ||
+        (rc = grow_pinned(c, s.h_sum, 8)) || (rc = grow_pinned(c, s.h_tab, ne * sizeof(redux_block))))
+        return rc;
+    uint64_t *ho = (uint64_t *)s.h_off.p;
+    for (uint64_t i = 0; i <= nb; i++)
+        ho[i] = D.in_offsets[blk_base + i] - sb0;
+    memcpy(s.h_tab.p, tbl.data(), ne * sizeof(redux_block));
+    HOST_TRY(hipMemcpyAsync(s.d_off.p, ho, (nb + 1) * 8, hipMemcpyHostToDevice, st));
+    HOST_TRY(hipMemcpyAsync(s.d_tab.p, s.h_tab.p, ne * sizeof(redux_block), hipMemcpyHostToDevice, st));
+    if (len_in && (rc = stage_h2d(c, pool, piece_no, s.d_in.p, D.in + sb0, len_in, st)))
+        return rc;
+    HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
+    uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
+    if ((rc = D.dev_call(D.p, s.d_in.p, s.d_off.p, ne, D.block_size, s.d_out.p, pos, s.d_sz.p, s.d_st.p, s.d_sum.p, ws, wsb, st, nullptr,
+                         (const redux_block *)s.d_tab.p, true, nb)))
+        return rc;
+    HOST_TRY(hipMemcpyAsync(s.h_sz.p, s.d_sz.p, nb * 4, hipMemcpyDeviceToHost, st));
+    HOST_TRY(hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st));
+    HOST_TRY(hipMemcpyAsync(s.h_sum.p, s.d_sum.p, 8, hipMemcpyDeviceToHost, st));
+    HOST_TRY(hipStreamSynchronize(st));
+    const uint32_t *hs = (const uint32_t *)s.h_sz.p;
+    // an input's blocks are back to back in both buffers: whole runs of full blocks leave as one copy
+    uint64_t b = 0;
+    for (uint64_t k = 0; k < G.i1 - G.i0; k++) {
+        const uint64_t cnt = redux_block_count(D.out_len[G.i0 + k], D.block_size);
+        for (uint64_t j = 0; j < cnt;) {
+            uint64_t run = 0, j1 = j;
+            while (j1 < cnt) { // extend over blocks that decoded to a whole block_size; the first shorter one ends the run
+                const uint32_t sz = hs[b + j1];
+                run += sz;
+                j1++;
+                if (sz != D.block_size)
+                    break;
+            }
+            if (run && (rc = drain_d2h(c, D.out + D.out_off[G.i0 + k] + j * (uint64_t)D.block_size,
+                                       (const uint8_t *)s.d_out.p + doff[k] + j * (uint64_t)D.block_size, run)))
+                return rc;
+            j = j1;
+        }
+        b += cnt;
+    }
+    memcpy(D.out_sizes + blk_base, hs, nb * 4);
+    if (D.block_status)
+        memcpy(D.block_status + blk_base, s.h_st.p, nb * 4);
+    J.bad[gi] = ((const int32_t *)s.h_sum.p)[0];
+    return REDUX_OK;
 }
 
 static int decode_blocks_v(const redux_params *p, const uint8_t *in, const uint64_t *in_offsets, uint8_t *out, const uint64_t *out_off,
                            const uint64_t *out_len, uint64_t ninputs, uint32_t block_size, uint32_t *out_sizes, int32_t *block_status,
                            DecodeDevCall dev_call)
 {
-    std::vector<Ctx *> ctx;
-    std::vector<std::unique_lock<std::mutex>> locks;
-    int rc = take_contexts(ctx, locks);
-    if (rc != REDUX_OK)
-        return rc;
-    Ctx &c = *ctx[0];
-    DeviceScope scope(c.want);
-    if ((rc = ctx_init_locked(c)) != REDUX_OK)
-        return rc;
-    Slot       &s  = c.slot[0];
-    hipStream_t st = c.stream[0];
-    CopyPool    pool(kCopyThreads - 1);
-    uint64_t    piece_no = 0, blk_base = 0;
-    int         first_bad = REDUX_OK;
-    std::vector<uint64_t>    doff;
-    std::vector<redux_block> tbl;
-    for (uint64_t i0 = 0; i0 < ninputs;) {
-        uint64_t i1 = i0, pos = 0;
-        doff.clear();
-        do {
-            doff.push_back(pos);
-            pos += (out_len[i1] + 15) & ~15ull;
-            i1++;
-        } while (i1 < ninputs && pos + out_len[i1] <= kVGroupBytes);
-        const uint64_t nb = redux_block_count_v(out_len + i0, i1 - i0, block_size);
-        const uint64_t ne = redux_block_table_v(doff.data(), out_len + i0, i1 - i0, block_size, nullptr);
-        tbl.resize(ne);
-        redux_block_table_v(doff.data(), out_len + i0, i1 - i0, block_size, tbl.data()); // offset = where the block goes, length = its room
-        const uint64_t sb0 = in_offsets[blk_base];
-        for (uint64_t i = 0; i < nb; i++)
-            if (in_offsets[blk_base + i + 1] < in_offsets[blk_base + i])
-                return REDUX_INVALID_INPUT;
-        const uint64_t len_in = in_offsets[blk_base + nb] - sb0;
-        if (len_in && !in)
-            return REDUX_INVALID_INPUT;
-        const uint64_t wsb = redux_decode_workspace_bytes(p, ne, block_size);
-        if ((rc = grow_dev(c, s.d_in, len_in + 32)) || (rc = grow_dev(c, s.d_ws, wsb + 256)) || (rc = grow_dev(c, s.d_out, pos + 16)) ||
-            (rc = grow_dev(c, s.d_off, (nb + 1) * 8)) || (rc = grow_dev(c, s.d_sz, nb * 4)) || (rc = grow_dev(c, s.d_st, nb * 4)) ||
-            (rc = grow_dev(c, s.d_sum, 8)) || (rc = grow_dev(c, s.d_tab, ne * sizeof(redux_block))) ||
-            (rc = grow_pinned(c, s.h_off, (nb + 1) * 8)) || (rc = grow_pinned(c, s.h_sz, nb * 4)) || (rc = grow_pinned(c, s.h_st, nb * 4)) ||
-            (rc = grow_pinned(c, s.h_sum, 8)) || (rc = grow_pinned(c, s.h_tab, ne * sizeof(redux_block))))
-            return rc;
-        uint64_t *ho = (uint64_t *)s.h_off.p;
-        for (uint64_t i = 0; i <= nb; i++)
-            ho[i] = in_offsets[blk_base + i] - sb0;
-        memcpy(s.h_tab.p, tbl.data(), ne * sizeof(redux_block));
-        HOST_TRY(hipMemcpyAsync(s.d_off.p, ho, (nb + 1) * 8, hipMemcpyHostToDevice, st));
-        HOST_TRY(hipMemcpyAsync(s.d_tab.p, s.h_tab.p, ne * sizeof(redux_block), hipMemcpyHostToDevice, st));
-        if (len_in && (rc = stage_h2d(c, pool, piece_no, s.d_in.p, in + sb0, len_in, st)))
-            return rc;
-        HOST_TRY(hipMemsetAsync(s.d_sum.p, 0, 8, st));
-        uint8_t *ws = (uint8_t *)(((uintptr_t)s.d_ws.p + 255) & ~(uintptr_t)255);
-        if ((rc = dev_call(p, s.d_in.p, s.d_off.p, ne, block_size, s.d_out.p, pos, s.d_sz.p, s.d_st.p, s.d_sum.p, ws, wsb, st, nullptr,
-                           (const redux_block *)s.d_tab.p, true, nb)))
-            return rc;
-        HOST_TRY(hipMemcpyAsync(s.h_sz.p, s.d_sz.p, nb * 4, hipMemcpyDeviceToHost, st));
-        HOST_TRY(hipMemcpyAsync(s.h_st.p, s.d_st.p, nb * 4, hipMemcpyDeviceToHost, st));
-        HOST_TRY(hipMemcpyAsync(s.h_sum.p, s.d_sum.p, 8, hipMemcpyDeviceToHost, st));
-        HOST_TRY(hipStreamSynchronize(st));
-        const uint32_t *hs = (const uint32_t *)s.h_sz.p;
-        // an input's blocks are back to back in both buffers: whole runs of full blocks leave as one copy
-        uint64_t b = 0;
-        for (uint64_t k = 0; k < i1 - i0; k++) {
-            const uint64_t cnt = redux_block_count(out_len[i0 + k], block_size);
-            for (uint64_t j = 0; j < cnt;) {
-                uint64_t run = 0, j1 = j;
-                while (j1 < cnt) { // extend over blocks that decoded to a whole block_size; the first shorter one ends the run
-                    const uint32_t sz = hs[b + j1];
-                    run += sz;
-                    j1++;
-                    if (sz != block_size)
-                        break;
-                }
-                if (run && (rc = drain_d2h(c, out + out_off[i0 + k] + j * (uint64_t)block_size,
-                                           (const uint8_t *)s.d_out.p + doff[k] + j * (uint64_t)block_size, run)))
-                    return rc;
-                j = j1;
-            }
-            b += cnt;
-        }
-        memcpy(out_sizes + blk_base, hs, nb * 4);
-        if (block_status)
-            memcpy(block_status + blk_base, s.h_st.p, nb * 4);
-        if (first_bad == REDUX_OK && ((const int32_t *)s.h_sum.p)[0] != REDUX_OK)
-            first_bad = ((const int32_t *)s.h_sum.p)[0];
-        blk_base += nb;
-        i0 = i1;
-    }
-    return first_bad;
+    const std::vector<VGroup> groups = v_groups(out_len, ninputs, block_size);
+    DecVCall D{p, in, in_offsets, out, out_off, out_len, block_size, out_sizes, block_status, dev_call};
+    VJob     J(groups.size());
+    return v_deal(groups.size(), J, [&](Ctx &c, size_t g, CopyPool &pool, uint64_t &piece_no) {
+        return decode_v_group(c, D, groups[g], g, J, pool, piece_no);
+    });
 }
 
 } // namespace host

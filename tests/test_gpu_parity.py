@@ -1232,6 +1232,16 @@ def test_host_calls_on_two_contexts_of_one_device(rx):
         assert o1.tobytes() == ref_out[: int(ref_offs[3])].tobytes() + ox.compress(small[3 * bs:].tobytes(), (8, 30, 32))[0]
         o2, of2, _, first = rx.compress_blocks_v([small.tobytes(), b"abc"], bs, (8, 30, 32))
         assert o2[: int(of2[4])].tobytes() == o1.tobytes()
+        # the batch calls deal their GROUPS of inputs over the fleet (group k on context k mod 3); with groups of 1 MiB every
+        # corpus is several groups, the dense output keeps block order through the ledger of group sizes
+        files = [open(p, "rb").read() for _, p in corpus_files("calgary", "canterbury")]
+        ref = rx.compress_blocks_v(files, bs, (8, 30, 32))
+        api.host_set_chunk_bytes(1 << 20, 1 << 20)
+        got = rx.compress_blocks_v(files, bs, (8, 30, 32))
+        assert (got[1] == ref[1]).all() and (got[0] == ref[0]).all() and (got[3] == ref[3]).all() and not got[2].any()
+        back, bsz, bst = rx.decompress_blocks_v(got[0], got[1], [len(f) for f in files], bs, (8, 30, 32))
+        assert not bst.any() and [b.tobytes() for b in back] == files
+        api.host_set_chunk_bytes(4 << 20, 4 << 20)
         with pytest.raises(rx.InvalidInput):
             api.host_set_devices([0, 99])
     finally:
