@@ -52,7 +52,7 @@ constexpr uint32_t kDecRcWindow = 1u << 20;
 // (scale_div's proof needs exactly that value) -- ~15 instructions of a step that has ~165.
 __device__ __forceinline__ double rc_lookup(rc_ptr rc, uint32_t rc_n, uint32_t nup, uint32_t count0)
 {
-    if (nup < rc_n) // (scalar branch)
+    if (__builtin_expect(nup < rc_n, 1)) // (scalar branch)
         return rc[nup];
     const double r = 1.0 / (double)(count0 + nup);
     return __longlong_as_double(__double_as_longlong(r) + 4);

@@ -5,17 +5,20 @@
 // a whole stream, the literal redux::decompress -- used to fall to k_decode: eight dependent LDS probes and a true
 // division per symbol on one lane, ~1 MB/s.  A launch that leaves most SIMDs idle can afford a wave per block, and then
 // get_symbol / update (adaptive_tree.rs:115-136, :83-92) are wave operations on the PLAIN cumulative table:
-//   * lane l holds cum(l + 1), cum(l + 65), cum(l + 129), cum(l + 193) -- the frequencies' inclusive prefix sums -- as
-//     u32 (any block length); the plane tops cum(64), cum(128), cum(192) are kept wave-uniform as well;
-//   * get_symbol(v): three scalar compares pick the plane, ONE v_cmp + ballot + popcount finds the lane where the table
-//     passes v; cum(s) and cum(s + 1) are two v_readlane;
-//   * update(s): every table entry above s grows by one: a compare + add-with-carry per plane, no memory at all;
+//   * lane l holds cum(4l + 1) .. cum(4l + 4) -- the frequencies' inclusive prefix sums of FOUR CONSECUTIVE symbols -- as
+//     u32 (any block length);
+//   * get_symbol(v): the symbol is the number of table entries that do not exceed v: four v_cmp + four scalar popcounts,
+//     no plane to select and no plane tops to maintain (round 3 kept the table as four planes of 64 and picked the plane
+//     with scalar compares: ~25 scalar instructions a step); cum(s) and cum(s + 1) are picked per lane by the same four
+//     compare masks and fetched with three v_readlane;
+//   * update(s): every table entry above s grows by one: a compare + add-with-carry per register, no memory at all;
 //   * the stream lives in a register across the lanes too (WaveBits): a refill is a v_readlane.
 // Everything else is k_decode's (the same order of the Eof / capacity checks, codec.rs:123-176), computed by the 64 lanes
-// on identical values; the three ways a block ends leave the loop by one branch.  1 MiB as one stream: 545 ms = 1.9 MB/s
-// (k_decode: ~1.1).  The step is ~200 instructions, most of them scalar -- a lone wave pays an issue slot for those too --
-// and has not been worked down as k_decode_lock's has: for blocks the lock-step decoder takes it is the slower one
-// (28.9 against 24 ms per 64 KiB block), so it is chosen only for the others, in launches of at most kWaveDecMaxBlocks.
+// on identical values; the three ways a block ends leave the loop by one branch.  Most of the step is scalar -- a lone wave
+// pays an issue slot for those instructions too -- so for blocks the lock-step decoder takes this one is not the faster
+// one, and it is chosen only for the others, in launches of at most kWaveDecMaxBlocks.  A serial adaptive stream has no
+// other parallelism: one CPU thread decodes ~19 MB/s, this kernel a tenth of that (INTEGRATION.md says so next to the
+// numbers).
 //
 // Included by redux_hip.hip (one translation unit).
 #pragma once
@@ -83,6 +86,13 @@ struct WaveBits {
         cnt -= skip;
         refill();
     }
+    // drop the next n (<= 32) bits; at least 33 valid bits are left in front afterwards
+    __device__ __forceinline__ void skip(uint32_t n)
+    {
+        bits <<= n;
+        cnt -= n;
+        refill();
+    }
     // next n (<= 32) bits, MSB first
     __device__ __forceinline__ uint32_t take(uint32_t n)
     {
@@ -118,11 +128,11 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
     const uint64_t stream_bits = size * 8;
     uint8_t       *dst         = a.out + dst_off;
     const rc_ptr   rcp         = (rc_ptr)a.rc;
-    const bool     aligned4    = a.aligned4 != 0 || ((((uintptr_t)dst) & 3) == 0);
 
-    // the model: inclusive prefix sums of the 256 data symbols' frequencies (all 1 at the start); EOF sits above them
-    uint32_t C0 = lane + 1, C1 = lane + 65, C2 = lane + 129, C3 = lane + 193;
-    uint32_t T0 = 64, T1 = 128, T2 = 192; // cum(64), cum(128), cum(192): wave-uniform
+    // the model: inclusive prefix sums of the 256 data symbols' frequencies (all 1 at the start), four consecutive
+    // symbols to a lane; EOF sits above them
+    const uint32_t L4 = 4u * lane, L4b = L4 + 1u, L4c = L4 + 2u, L4d = L4 + 3u; // the entries' numbers
+    uint32_t C0 = L4 + 1, C1 = L4 + 2, C2 = L4 + 3, C3 = L4 + 4;
 
     WaveBits B;
     B.init(sp, size, lane);
@@ -136,7 +146,6 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
         done = true;
     }
     uint32_t n_out = 0;
-    uint32_t obuf  = 0;
 
     // One way through the step: everything is computed and the three ways a block ends -- the EOF symbol (codec.rs:136-138,
     // decided first: decompress_symbol returns before renormalising), a stream that runs dry in the renormalisation
@@ -146,21 +155,37 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
     double   rc_next = rcp[0]; // the reciprocal of step p + 1 is loaded during step p (a lone wave hides no latency by itself)
     uint32_t p       = 0;
     bool     eof = false, dry = false;
-    uint64_t cons2 = consumed;
+    // stream bits not pulled yet, as a 32-bit count-down (a block is below 4 GiB, so stream_bits < 2^35: the count-down is
+    // clamped to 2^31 - 1 and topped up from the rest whenever it has dropped below 2^30; a step pulls at most 64 bits)
+    uint64_t rest = stream_bits - (done ? stream_bits : consumed);
+    uint32_t left = rest > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)rest;
+    rest -= left;
+    uint32_t n = 0;
     if (!done) {
         for (;; p++) {
             const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
-            const double   rc  = rc_next;
-            rc_next            = rc_lookup(rcp, a.rc_n, p + 1 < a.nfreeze ? p + 1 : a.nfreeze, 257u); // (computed past the table's window)
+            double         rc  = rc_next;
+            if (__builtin_expect(nup >= a.rc_n, 0)) // past the table's window: computed as k_fill_rc computes an entry (rc_lookup)
+                rc = rc_lookup(rcp, 0, nup, 257u);
+            {   // (the load is unconditional -- its index clamped into the table -- and nothing waits for it before the next step)
+                const uint32_t nx = p + 1 < a.nfreeze ? p + 1 : a.nfreeze;
+                rc_next           = rcp[nx < a.rc_n ? nx : a.rc_n];
+            }
             const uint32_t c   = 257u + nup;
             // value = ((pending - low + 1) * count - 1) / range      (codec.rs:129-131)
             const uint32_t R1 = (high - low) >> sh;
             const uint32_t Vd = (W - low) >> sh;
             uint32_t       v;
             if (FIXUP) {
+                // count up to 2^30: the numerator has up to 62 bits.  The quotient (< count) is estimated with a reciprocal
+                // refined by one Newton step (relative error ~2^-48: the estimate is within 1) and settled by the exact
+                // 64-bit remainder -- where a true f64 division would spend a dozen instructions to round a quotient that
+                // is only an estimate anyway.
                 const uint64_t num = ((uint64_t)Vd + 1) * c - 1;
                 const double   xd  = (double)R1 + 1.0;
-                v                  = (uint32_t)((double)num / xd);
+                double         ri  = __builtin_amdgcn_rcp(xd);
+                ri                 = __builtin_fma(__builtin_fma(-xd, ri, 1.0), ri, ri);
+                v                  = (uint32_t)((double)num * ri);
                 const int64_t r    = (int64_t)(num - ((uint64_t)v * R1 + v));
                 v += r < 0 ? 0xFFFFFFFFu : ((uint64_t)r > (uint64_t)R1 ? 1u : 0u);
             } else {
@@ -168,22 +193,35 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
             }
             const uint32_t vu = __builtin_amdgcn_readfirstlane(v); // (the same in every lane: scalar from here on)
             eof               = vu >= c - 1;                          // tree[256] = count - 1: the EOF symbol
-            // get_symbol (adaptive_tree.rs:115-136) on the plain table
-            const uint32_t pq   = (vu >= T0 ? 1u : 0u) + (vu >= T1 ? 1u : 0u) + (vu >= T2 ? 1u : 0u);
-            const uint32_t X    = pq == 0 ? C0 : pq == 1 ? C1 : pq == 2 ? C2 : C3;
-            const uint32_t b    = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(X <= vu)); // < 64 unless EOF: the plane's top is above v
-            const uint32_t s    = 64u * pq + b;
-            const uint32_t hi   = __builtin_amdgcn_readlane(X, b & 63u);
-            const uint32_t base = pq == 0 ? 0u : pq == 1 ? T0 : pq == 2 ? T1 : T2;
-            const uint32_t lo   = b ? __builtin_amdgcn_readlane(X, (b - 1u) & 63u) : base;
-            if (p < a.nfreeze) { // update(s + 1), adaptive_tree.rs:83-92: every prefix sum above s grows by one
-                C0 += lane >= s ? 1u : 0u;
-                C1 += lane + 64u >= s ? 1u : 0u;
-                C2 += lane + 128u >= s ? 1u : 0u;
-                C3 += lane + 192u >= s ? 1u : 0u;
-                T0 += s < 64u ? 1u : 0u;
-                T1 += s < 128u ? 1u : 0u;
-                T2 += s < 192u ? 1u : 0u;
+            // get_symbol (adaptive_tree.rs:115-136) on the plain table: s = how many of the 256 prefix sums v has reached
+            const bool     g0 = C0 <= vu, g1 = C1 <= vu, g2 = C2 <= vu, g3 = C3 <= vu;
+            const uint32_t bl = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(g3)); // lanes wholly at or below v
+            const uint32_t s  = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(g0)) +
+                               (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(g1)) +
+                               (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(g2)) + bl;
+            // cum(s + 1) and cum(s) sit in lane bl (s = 4 bl + w): picked per lane by the same masks, fetched by readlane;
+            // for w == 0 the low end is the lane before's last entry (0 in front of the table)
+            const uint32_t hi_l = g0 ? (g1 ? (g2 ? C3 : C2) : C1) : C0;
+            const uint32_t lo_l = g1 ? (g2 ? C2 : C1) : C0;
+            const uint32_t hi   = __builtin_amdgcn_readlane(hi_l, bl & 63u);
+            const uint32_t loin = __builtin_amdgcn_readlane(lo_l, bl & 63u);
+            const uint32_t prev = __builtin_amdgcn_readlane(C3, (bl - 1u) & 63u);
+            const uint32_t lo   = (s & 3u) ? loin : (bl ? prev : 0u);
+            { // update(s + 1), adaptive_tree.rs:83-92: every prefix sum above s grows by one (not once the model is frozen).
+              // The four compares first, then the four adds-with-carry: written as compare + add pairs the compiler puts a
+              // wait state between each compare and the add that reads its mask.
+                const uint32_t su = p < a.nfreeze ? s : 0xFFFFFFFFu;
+                uint64_t       m0, m1, m2, m3;
+                asm("v_cmp_le_u32_e64 %4, %8, %9\n\t"
+                    "v_cmp_le_u32_e64 %5, %8, %10\n\t"
+                    "v_cmp_le_u32_e64 %6, %8, %11\n\t"
+                    "v_cmp_le_u32_e64 %7, %8, %12\n\t"
+                    "v_addc_co_u32_e64 %0, %4, 0, %0, %4\n\t"
+                    "v_addc_co_u32_e64 %1, %5, 0, %1, %5\n\t"
+                    "v_addc_co_u32_e64 %2, %6, 0, %2, %6\n\t"
+                    "v_addc_co_u32_e64 %3, %7, 0, %3, %7"
+                    : "+v"(C0), "+v"(C1), "+v"(C2), "+v"(C3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                    : "s"(su), "v"(L4), "v"(L4b), "v"(L4c), "v"(L4d));
             }
             const double   Y     = __builtin_fma((double)R1, rc, rc);
             const uint32_t nlow  = low + (scale_div<FIXUP>(R1, Y, lo, c) << sh);
@@ -194,42 +232,43 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
             const uint32_t ih2   = (uint32_t)((uint64_t)(~nhigh) << k);
             const uint32_t t     = (low2 & ih2) << 1;
             const uint32_t j     = (uint32_t)__builtin_clz(~t);
-            const uint32_t n     = k + j; // bits pulled by get_bit (codec.rs:157)
-            cons2                = consumed + n;
-            dry                  = cons2 > stream_bits; // read_bits would hit Err(Eof) (bitio/mod.rs:107)
+            n                    = k + j; // bits pulled by get_bit (codec.rs:157)
+            dry                  = n > left; // read_bits would hit Err(Eof) (bitio/mod.rs:107)
             if (__builtin_expect(eof || dry || p >= capn, 0))
                 break;
-            consumed = cons2;
-            low      = (low2 << j) & 0x7FFFFFFFu;
-            high     = ~((ih2 << j) & 0x7FFFFFFFu);
-            // k E1/E2 steps shift the value left, each of the j E3 steps drops the bit below the top one (k_decode)
-            const uint32_t nb   = B.take(n);
-            const uint64_t comb = ((uint64_t)W << 32) | ((uint64_t)nb << (32 + sh - n));
-            const uint64_t c1   = comb << k;
-            const uint64_t c2   = c1 << j;
-            W = (((uint32_t)(c2 >> 32) & 0x7FFFFFFFu) | ((uint32_t)(c1 >> 32) & 0x80000000u)) & (0xFFFFFFFFu << sh);
-            // emit the symbol (write_bits(symbol, 8), codec.rs:171); every lane stores the same dword to the same address
-            // (no exec mask, no branch around it: the requests merge)
-            if (aligned4) {
-                obuf |= s << (8 * (p & 3));
-                if ((p & 3) == 3) {
-                    *reinterpret_cast<uint32_t *>(dst + (p & ~3u)) = obuf;
-                    obuf = 0;
+            left -= n;
+            if (__builtin_expect(rest != 0, 0)) { // (streams beyond 256 MiB only)
+                if (left < 0x40000000u) {
+                    const uint64_t add = rest > 0x3FFFFFFFull ? 0x3FFFFFFFull : rest;
+                    left += (uint32_t)add;
+                    rest -= add;
                 }
-            } else {
-                dst[p] = (uint8_t)s;
             }
+            low  = (low2 << j) & 0x7FFFFFFFu;
+            high = ~((ih2 << j) & 0x7FFFFFFFu);
+            // [value | next 32 stream bits] << k, keep the top bit, << j, put it back: k E1/E2 steps shift the value left, each
+            // of the j E3 steps drops the bit below the top one (codec.rs:143-157; k_decode_lock's form: the bits are taken
+            // from the reader's look-ahead in place, then the reader moves on)
+            const uint32_t nxt  = (uint32_t)(B.bits >> 32);
+            const uint64_t comb = ((uint64_t)W << 32) | ((uint64_t)nxt << sh);
+            const uint32_t h2   = (uint32_t)((comb << n) >> 32);
+            const uint32_t h1   = (uint32_t)((comb << k) >> 32);
+            W = ((h2 & 0x7FFFFFFFu) | (h1 & 0x80000000u)) & (0xFFFFFFFFu << sh);
+            B.skip(n);
+            // emit the symbol (write_bits(symbol, 8), codec.rs:171): every lane stores the same byte to the same address (no
+            // exec mask, no branch around it: the requests merge; a byte per ~700 cycles is nothing to the memory system)
+            dst[p] = (uint8_t)s;
         }
-        if (!eof) { // the renormalisation was entered: its bits count as consumed whichever way the step failed
-            consumed = cons2;
-            st       = dry ? REDUX_EOF : REDUX_OUTPUT_TOO_SMALL;
+        // bits pulled when the loop was left: the steps before this one, plus -- unless it ended on the EOF symbol, which
+        // returns before renormalising -- this step's own (its renormalisation was entered whichever way it failed)
+        consumed = stream_bits - rest - left;
+        if (!eof) {
+            consumed += n;
+            st = dry ? REDUX_EOF : REDUX_OUTPUT_TOO_SMALL;
         }
     }
     n_out = p; // every committed step emitted one symbol
     if (lane == 0) {
-        if (aligned4)
-            for (uint32_t i = n_out & ~3u; i < n_out; i++)
-                dst[i] = (uint8_t)(obuf >> (8 * (i & 3)));
         a.out_sizes[blk] = n_out;
         a.status[blk]    = st;
         if (a.in_used) { // the reader fetches whole bytes, and never past the end of the stream
