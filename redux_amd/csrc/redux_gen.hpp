@@ -202,6 +202,70 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
 
     EncState S;
     enc_init(S, off0);
+
+    // ---- whole waves: turns of 32 symbols (= SB dwords of input per lane), every lane alive, no predicate ----------------
+    // As k_encode's chunks (redux_encode.hpp): the turn's input dwords are loaded a turn ahead, its symbols sit at static bit
+    // positions (read_bits(SB) MSB-first, bitio/mod.rs:78-120), the reciprocals come eight at a time, and the coder is
+    // encode_symbol_fast -- one store site, the long-pending-run case found by one wave-level ballot -- instead of the
+    // per-lane predicated encode_symbol, whose store sites under branches make every vector-memory wait a full one.  Runs while
+    // every lane has the symbols, the model still updates (a frozen model's tail is the loop below) and the count stays below
+    // 2^17 (no quotient fix-up, scale_div); 4-byte aligned blocks only.
+    uint32_t p = 0;
+    if (SB < 8) {
+        constexpr uint32_t U = 32;
+        const bool     whole  = __builtin_amdgcn_ballot_w64(live) == ~0ull;
+        const uint32_t minsym = __builtin_amdgcn_readfirstlane(wave_min(live ? nsym : 0u));
+        uint32_t       e      = minsym < nfreeze ? minsym : nfreeze;
+        constexpr uint32_t kNoFix = (1u << 17) - kCount0;
+        e                     = e < kNoFix ? e : kNoFix;
+        const uint32_t fast_end = (whole && (((uintptr_t)a.in | a.block_size) & 3u) == 0) ? (e & ~(U - 1u)) : 0u;
+        if (fast_end) {
+            constexpr uint32_t kBudget = U * 4 + 32; // bytes a turn may add on the common path (one dword per symbol at most) + slack
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(src);
+            uint32_t        cur[SB], nxt[SB];
+#pragma unroll
+            for (int d = 0; d < SB; d++)
+                cur[d] = wp[d];
+            for (; p < fast_end; p += U) {
+                if (__builtin_amdgcn_ballot_w64(S.off + kBudget > limit))
+                    break; // a slot is nearly full: the checked loop below finishes the block
+                {
+                    const uint32_t t = p + U < fast_end ? (p + U) / U : p / U; // (the last turn re-reads its own dwords)
+#pragma unroll
+                    for (int d = 0; d < SB; d++)
+                        nxt[d] = wp[t * SB + d];
+                }
+                uint32_t be[SB];
+#pragma unroll
+                for (int d = 0; d < SB; d++)
+                    be[d] = __builtin_bswap32(cur[d]);
+#pragma unroll
+                for (uint32_t h = 0; h < U / 8; h++) {
+                    double r[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        r[i] = rc[p + 8 * h + i];
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; i++) {
+                        const uint32_t k = 8 * h + i, o = k * SB, d = o >> 5, rr = o & 31u;
+                        uint32_t       sym;
+                        if (rr + SB <= 32)
+                            sym = (be[d] >> (32 - rr - SB)) & Tree::kMask;
+                        else
+                            sym = ((be[d] << (rr + SB - 32)) | (be[d + 1 < SB ? d + 1 : d] >> (64 - rr - SB))) & Tree::kMask;
+                        uint32_t lo, hi;
+                        T.get_frequency(sym, p + k, true, lo, hi);
+                        encode_symbol_fast<false>(S, lo, hi, kCount0 + p + k, r[i], sh, wdst);
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < SB; d++)
+                    cur[d] = nxt[d];
+            }
+        }
+    }
+
+    // ---- the rest, symbol by symbol with per-lane predicates (ragged blocks, frozen models, the EOF symbol) ----------------
     // The symbol and the reciprocal of step p + 1 are loaded during step p: one wave per CU has nothing else to hide a
     // load behind.  The symbol's load is unconditional (index clamped into the block; a lane without symbols reads its
     // block's first bytes, or the buffer's for an empty input... never past what a.in holds), so that it is not followed
@@ -210,9 +274,10 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
     const bool     can_load = live && nsym != 0;
     const uint8_t *psrc     = can_load ? src : reinterpret_cast<const uint8_t *>(a.rc); // (always mapped, at least 33 doubles)
     const uint32_t lastb    = can_load ? len - 1u : 2u;
-    uint32_t       raw_next = gen_symbol_load<SB>(psrc, 0, lastb), k_next = 0;
-    double         r_next   = rc[0];
-    for (uint32_t p = 0; p <= maxsym; p++) {
+    uint32_t       k_next   = can_load ? (p < last_sym ? p : last_sym) : 0u;
+    uint32_t       raw_next = gen_symbol_load<SB>(psrc, k_next, lastb);
+    double         r_next   = rc[p < nfreeze ? p : nfreeze];
+    for (; p <= maxsym; p++) {
         const uint32_t nup = p < nfreeze ? p : nfreeze; // wave-uniform
         const double   r   = r_next;
         const uint32_t c   = kCount0 + nup;
