@@ -92,22 +92,32 @@ struct GenTree {
     }
     // the share of levels [B0, B1) in get_frequency(s): fetch-adds and masked sums of those levels only; the level-
     // independent terms (s, s + 1, the derived node) ride with the share that starts at level 0.  The shares of a
-    // partition of the levels add up to get_frequency's (low, high).
+    // partition of the levels add up to get_frequency's (low, high).  In two halves, so that a loop can put the NEXT
+    // symbol's fetch-adds into the LDS queue before it consumes this symbol's values (the queue is in order: the next
+    // symbol's fetch-adds see this symbol's increments).
+    struct Nodes {
+        uint32_t x[SB];
+    };
     template <int B0, int B1>
-    __device__ __forceinline__ void get_frequency_part(uint32_t s, uint32_t nup, bool upd, uint32_t &lo, uint32_t &hi) const
+    __device__ __forceinline__ Nodes issue_part(uint32_t s, bool upd) const
     {
-        uint32_t       x[SB];
-        const uint32_t m = s + 1;
+        Nodes n;
 #pragma unroll
         for (int b = B0; b < B1; b++) {
             const uint32_t e = (s | (1u << b)) & (kMask << b);
-            x[b]             = fetch_add(e, (upd && !((s >> b) & 1u)) ? 1u : 0u);
+            n.x[b]           = fetch_add(e, (upd && !((s >> b) & 1u)) ? 1u : 0u);
         }
-        uint32_t ls = B0 == 0 ? s : 0u, hs = B0 == 0 ? m + (m >> SB) * nup : 0u;
+        return n;
+    }
+    template <int B0, int B1>
+    __device__ __forceinline__ void finish_part(uint32_t s, uint32_t nup, const Nodes &n, uint32_t &lo, uint32_t &hi) const
+    {
+        const uint32_t m  = s + 1;
+        uint32_t       ls = B0 == 0 ? s : 0u, hs = B0 == 0 ? m + (m >> SB) * nup : 0u;
 #pragma unroll
         for (int b = B0; b < B1; b++) {
-            ls += ((s >> b) & 1u) ? x[b] : 0u;
-            hs += ((m >> b) & 1u) ? x[b] : 0u;
+            ls += ((s >> b) & 1u) ? n.x[b] : 0u;
+            hs += ((m >> b) & 1u) ? n.x[b] : 0u;
         }
         lo = ls;
         hi = hs;
@@ -333,9 +343,15 @@ __global__ void __launch_bounds__(256) k_encode_gen_pair(GenEncArgs a)
     }
     const uint32_t nsym    = (uint32_t)(((uint64_t)len * 8) / SB); // whole symbols; trailing bits are dropped (codec.rs:108)
     const uint32_t maxsym  = __builtin_amdgcn_readfirstlane(wave_max(live ? nsym : 0u));
+    const uint32_t minsym  = __builtin_amdgcn_readfirstlane(wave_min(live ? nsym : 0xFFFFFFFFu));
+    const bool     whole   = __builtin_amdgcn_ballot_w64(live) == (Tree::kBlocks == 64 ? ~0ull : (1ull << Tree::kBlocks) - 1ull);
     const uint32_t nfreeze = a.nfreeze;
     const uint32_t nper    = (maxsym + 1 + kHalf - 1) / kHalf; // symbols 0 .. maxsym (the longest block's EOF)
     constexpr uint32_t kCount0 = (1u << SB) + 1u;
+    // Lanes without a block leave here (a wave of 12-bit symbols has 16 blocks): what is left of each wave runs with a
+    // shorter exec mask, so the coder wave's unpredicated path below stores nothing for them.  (The barriers count waves.)
+    if (lane >= Tree::kBlocks)
+        return;
 
     if (wave < kModelWaves) {
         // ---------------- model waves ----------------
@@ -348,27 +364,75 @@ __global__ void __launch_bounds__(256) k_encode_gen_pair(GenEncArgs a)
         const uint32_t lastb    = can_load ? len - 1u : 2u;
         uint32_t       raw_next = gen_symbol_load<SB>(psrc, 0, lastb), k_next = 0;
         uint2         *my       = ring[wave];
+        auto part = [&](uint32_t sym, uint32_t nup, bool upd, uint32_t &lo, uint32_t &hi) {
+            if (wave == 0)
+                T.template finish_part<0, kSplit1>(sym, nup, T.template issue_part<0, kSplit1>(sym, upd), lo, hi);
+            else if (wave == 1)
+                T.template finish_part<kSplit1, kSplit2>(sym, nup, T.template issue_part<kSplit1, kSplit2>(sym, upd), lo, hi);
+            else
+                T.template finish_part<kSplit2, SB>(sym, nup, T.template issue_part<kSplit2, SB>(sym, upd), lo, hi);
+        };
+        // The eight symbols of a half are exactly SB bytes of the block, from byte t * SB on: a half whose bytes -- and the next
+        // half's -- lie inside EVERY lane's block takes them from (up to three, unaligned) dwords loaded a half earlier, at
+        // static bit positions.  (Loading a symbol's two bytes one step ahead, as the other halves do, leaves the load's latency
+        // exposed once per symbol: that, not the fetch-adds, was what a step of this kernel waited for.)
+        constexpr int kW = (SB + 3) / 4; // dwords that hold a half's SB bytes
+        uint32_t      w[kW], wn[kW];
+        bool          have_w = false;
         for (uint32_t t = 0; t < nper; t++) {
+            // (whole: every lane of the workgroup has a block; the bytes read reach at most 3 past the next half's: inside the block)
+            if (whole && ((uint64_t)(t + 2) * SB + 4 <= (uint64_t)minsym * SB / 8)) {
+                const uint8_t *hp = src + (uint64_t)t * SB;
+                if (!have_w) {
 #pragma unroll
-            for (uint32_t i = 0; i < kHalf; i++) {
-                const uint32_t p   = t * kHalf + i;
-                const uint32_t nup = p < nfreeze ? p : nfreeze; // wave-uniform
-                const uint32_t sym = gen_symbol_decode<SB>(raw_next, k_next);
-                {
-                    const uint32_t q = p + 1 < last_sym ? p + 1 : last_sym;
-                    k_next           = can_load ? q : 0u;
-                    raw_next         = gen_symbol_load<SB>(psrc, k_next, lastb);
+                    for (int d = 0; d < kW; d++)
+                        w[d] = *reinterpret_cast<const uint32_t *>(hp + 4 * d);
                 }
-                uint32_t lo = 0, hi = 0;
-                if (live && p < nsym) {
-                    if (wave == 0)
-                        T.template get_frequency_part<0, kSplit1>(sym, nup, p < nfreeze, lo, hi);
-                    else if (wave == 1)
-                        T.template get_frequency_part<kSplit1, kSplit2>(sym, nup, p < nfreeze, lo, hi);
+#pragma unroll
+                for (int d = 0; d < kW; d++)
+                    wn[d] = *reinterpret_cast<const uint32_t *>(hp + SB + 4 * d);
+                uint32_t be[kW];
+#pragma unroll
+                for (int d = 0; d < kW; d++)
+                    be[d] = __builtin_bswap32(w[d]);
+#pragma unroll
+                for (uint32_t i = 0; i < kHalf; i++) {
+                    const uint32_t p   = t * kHalf + i;
+                    const uint32_t nup = p < nfreeze ? p : nfreeze; // wave-uniform
+                    const uint32_t o = i * SB, d = o >> 5, rr = o & 31u;
+                    uint32_t       sym;
+                    if (rr + SB <= 32)
+                        sym = (be[d] >> (32 - rr - SB)) & Tree::kMask;
                     else
-                        T.template get_frequency_part<kSplit2, SB>(sym, nup, p < nfreeze, lo, hi);
+                        sym = ((be[d] << (rr + SB - 32)) | (be[d + 1 < kW ? d + 1 : d] >> (64 - rr - SB))) & Tree::kMask;
+                    uint32_t lo, hi;
+                    part(sym, nup, p < nfreeze, lo, hi);
+                    my[((t & 1u) * kHalf + i) * 64 + lane] = make_uint2(lo, hi);
                 }
-                my[((t & 1u) * kHalf + i) * 64 + lane] = make_uint2(lo, hi);
+#pragma unroll
+                for (int d = 0; d < kW; d++)
+                    w[d] = wn[d];
+                have_w = true;
+                // (the per-symbol loader below continues behind this half)
+                k_next   = (t + 1) * kHalf < last_sym ? (t + 1) * kHalf : last_sym;
+                raw_next = gen_symbol_load<SB>(psrc, k_next, lastb);
+            } else {
+                have_w = false;
+#pragma unroll
+                for (uint32_t i = 0; i < kHalf; i++) {
+                    const uint32_t p   = t * kHalf + i;
+                    const uint32_t nup = p < nfreeze ? p : nfreeze; // wave-uniform
+                    const uint32_t sym = gen_symbol_decode<SB>(raw_next, k_next);
+                    {
+                        const uint32_t q = p + 1 < last_sym ? p + 1 : last_sym;
+                        k_next           = can_load ? q : 0u;
+                        raw_next         = gen_symbol_load<SB>(psrc, k_next, lastb);
+                    }
+                    uint32_t lo = 0, hi = 0;
+                    if (live && p < nsym)
+                        part(sym, nup, p < nfreeze, lo, hi);
+                    my[((t & 1u) * kHalf + i) * 64 + lane] = make_uint2(lo, hi);
+                }
             }
             pair_barrier();
         }
@@ -393,6 +457,17 @@ __global__ void __launch_bounds__(256) k_encode_gen_pair(GenEncArgs a)
         }
         // (count <= 2^SB + 1 + 65535 < 2^17 for the u16 trees: the quotients need no fix-up, scale_div)
         constexpr bool kFix = (1u << SB) + 1u + Tree::kMaxSymbols >= (1u << 17);
+        // a half in which every lane codes a data symbol, with room for a dword per symbol: straight-line, one store site,
+        // the long-pending-run case found by a wave-level ballot (encode_symbol_fast) instead of the predicated encode_symbol
+        if (whole && (t + 1) * kHalf <= minsym && __builtin_amdgcn_ballot_w64(S.off + kHalf * 4 + 32 > limit) == 0) {
+#pragma unroll
+            for (uint32_t i = 0; i < kHalf; i++) {
+                const uint32_t p   = t * kHalf + i;
+                const uint32_t nup = p < nfreeze ? p : nfreeze;
+                encode_symbol_fast<kFix>(S, lh[i].x, lh[i].y, kCount0 + nup, rc[nup], sh, wdst);
+            }
+            continue;
+        }
 #pragma unroll
         for (uint32_t i = 0; i < kHalf; i++) {
             const uint32_t p   = t * kHalf + i;
