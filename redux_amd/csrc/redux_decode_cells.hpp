@@ -25,10 +25,12 @@
 //     descent's own masks, written back with ONE 16-byte store (u32 nodes: two).  No atomics: a lane owns its cells.
 //   * where the cells live.  Groups above the bottom one: LDS, lane l owning 16 bytes of every piece row (conflict-free
 //     for any per-lane cell).  The bottom group (2^(symbol_bits - 4) cells per block: 8 KiB for 12-bit symbols) in LDS
-//     too when it fits -- symbol_bits <= 10, or fewer lanes per wave: 16 for 12-bit symbols, 32 for 11 -- and otherwise
-//     (GLOBAL0: large grids of 11- and 12-bit symbols) in the workspace, block-major, one 32-byte sector per cell: a
-//     step is then two LDS round trips and ONE global round trip where k_decode_gen<12, false> made twelve dependent
-//     global probes and twelve global atomics, and 64 blocks per wave, four waves per CU stay in flight.
+//     too while 64 blocks' worth fits -- symbol_bits <= 10 -- and otherwise (GLOBAL0: 11- and 12-bit symbols) in the
+//     workspace, block-major, one 32-byte sector per cell: a step is then two LDS round trips and ONE global round trip
+//     where round 3's k_decode_gen<12, false> made twelve dependent global probes and twelve global atomics, and 64
+//     blocks per wave, four waves per CU stay in flight.  (All-LDS forms with fewer lanes per wave -- 16 for 12-bit
+//     symbols, 32 for 11 -- were built and measured: never faster from 2,048 blocks up, half the speed where they need
+//     a second pass over the chip; the template still takes LANES < 64.)
 //   * everything else as k_decode_lock: the stream through a ring of 16 dwords per lane in LDS fed by one unconditional
 //     16-byte load per four steps; the code value by v_rcp_f64 + one exact remainder; closed-form renormalisation; every
 //     lane computes and commits every step, a lane that ends (EOF symbol, codec.rs:136-138; stream exhausted,

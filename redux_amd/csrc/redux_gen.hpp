@@ -26,6 +26,8 @@
 #pragma once
 
 #include "redux_coder.hpp"
+
+#include <type_traits>
 #include "redux_decode.hpp" // BitIn
 #include "redux_encode.hpp" // wave_max
 
@@ -218,16 +220,15 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
     // positions (read_bits(SB) MSB-first, bitio/mod.rs:78-120), the reciprocals come eight at a time, and the coder is
     // encode_symbol_fast -- one store site, the long-pending-run case found by one wave-level ballot -- instead of the
     // per-lane predicated encode_symbol, whose store sites under branches make every vector-memory wait a full one.  Runs while
-    // every lane has the symbols, the model still updates (a frozen model's tail is the loop below) and the count stays below
-    // 2^17 (no quotient fix-up, scale_div); 4-byte aligned blocks only.
+    // every lane has the symbols and the count stays below 2^17 (no quotient fix-up, scale_div; a model that freezes below
+    // that never leaves the loop for it); 4-byte aligned blocks only.
     uint32_t p = 0;
     if (SB < 8) {
         constexpr uint32_t U = 32;
         const bool     whole  = __builtin_amdgcn_ballot_w64(live) == ~0ull;
         const uint32_t minsym = __builtin_amdgcn_readfirstlane(wave_min(live ? nsym : 0u));
-        uint32_t       e      = minsym < nfreeze ? minsym : nfreeze;
         constexpr uint32_t kNoFix = (1u << 17) - kCount0;
-        e                     = e < kNoFix ? e : kNoFix;
+        const uint32_t e      = (nfreeze < kNoFix || minsym < kNoFix) ? minsym : kNoFix; // (a model that freezes below 2^17 never needs the fix-up)
         const uint32_t fast_end = (whole && (((uintptr_t)a.in | a.block_size) & 3u) == 0) ? (e & ~(U - 1u)) : 0u;
         if (fast_end) {
             constexpr uint32_t kBudget = U * 4 + 32; // bytes a turn may add on the common path (one dword per symbol at most) + slack
@@ -236,7 +237,11 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
 #pragma unroll
             for (int d = 0; d < SB; d++)
                 cur[d] = wp[d];
-            for (; p < fast_end; p += U) {
+            // (the loop exists twice: while every symbol of a turn updates the model -- count and reciprocal by induction --, and
+            // with both selected per symbol for the turns from the freeze point on)
+            auto turns = [&](auto frozen_tag, const uint32_t pend) {
+            constexpr bool FRZ = decltype(frozen_tag)::value;
+            for (; p < pend; p += U) {
                 if (__builtin_amdgcn_ballot_w64(S.off + kBudget > limit))
                     break; // a slot is nearly full: the checked loop below finishes the block
                 {
@@ -253,8 +258,10 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
                 for (uint32_t h = 0; h < U / 8; h++) {
                     double r[8];
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        r[i] = rc[p + 8 * h + i];
+                    for (int i = 0; i < 8; i++) {
+                        const uint32_t q = p + 8 * h + i;
+                        r[i]             = rc[FRZ ? (q < nfreeze ? q : nfreeze) : q];
+                    }
 #pragma unroll
                     for (uint32_t i = 0; i < 8; i++) {
                         const uint32_t k = 8 * h + i, o = k * SB, d = o >> 5, rr = o & 31u;
@@ -263,15 +270,21 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
                             sym = (be[d] >> (32 - rr - SB)) & Tree::kMask;
                         else
                             sym = ((be[d] << (rr + SB - 32)) | (be[d + 1 < SB ? d + 1 : d] >> (64 - rr - SB))) & Tree::kMask;
-                        uint32_t lo, hi;
-                        T.get_frequency(sym, p + k, true, lo, hi);
-                        encode_symbol_fast<false>(S, lo, hi, kCount0 + p + k, r[i], sh, wdst);
+                        const uint32_t nup = FRZ ? (p + k < nfreeze ? p + k : nfreeze) : p + k; // wave-uniform; past the freeze point nothing updates
+                        uint32_t       lo, hi;
+                        T.get_frequency(sym, nup, FRZ ? p + k < nfreeze : true, lo, hi);
+                        encode_symbol_fast<false>(S, lo, hi, kCount0 + nup, r[i], sh, wdst);
                     }
                 }
 #pragma unroll
                 for (int d = 0; d < SB; d++)
                     cur[d] = nxt[d];
             }
+            };
+            const uint32_t a_end = fast_end < (nfreeze & ~(U - 1u)) ? fast_end : (nfreeze & ~(U - 1u));
+            turns(std::false_type(), a_end);
+            if (p == a_end && a_end < fast_end) // (not left early for a full slot)
+                turns(std::true_type(), fast_end);
         }
     }
 

@@ -171,13 +171,17 @@ static bool is_gen(const redux_params *p, uint32_t block_size)
         return false;
     return p->symbol_bits == 4 || gen_decode_cells(p, block_size);
 }
-// 11- and 12-bit symbols: the bottom cells (4 / 8 KiB per block) live in LDS on small grids -- 32 / 16 blocks per wave, one
-// wave per CU -- and in the workspace on large ones (64 blocks per wave, four waves per CU): redux_decode_cells.hpp
+// 11- and 12-bit symbols: the bottom cells (2^(symbol_bits - 4) of 32 bytes per block: 4 / 8 KiB) live in the workspace, the
+// cells above them in LDS: 64 blocks per wave, four waves per CU (redux_decode_cells.hpp).  Measured against keeping everything
+// in LDS (which holds 16 blocks of 12-bit symbols per CU, 32 of 11-bit): never slower from 2,048 blocks up, 2 x faster where
+// the LDS form needs a second pass.  9- and 10-bit symbols fit LDS with 64 blocks per wave and are faster there
+// (profiles/r04_gen_parameters.txt).
 static bool gen_decode_in_workspace(const redux_params *p, uint64_t nblocks)
 {
-    return (p->symbol_bits == 12 && nblocks >= 16384) || (p->symbol_bits == 11 && nblocks >= 32768);
+    (void)nblocks;
+    return p->symbol_bits >= 11;
 }
-static uint64_t gen_decode_tree_bytes(const redux_params *p) { return p->symbol_bits == 12 ? CellGeom<12, 64, true>::kTreeBytes : CellGeom<11, 64, true>::kTreeBytes; }
+static uint64_t gen_decode_tree_bytes(const redux_params *p) { return (1ull << (p->symbol_bits - 4)) * 32; }
 
 static uint64_t slot_cap_for(const redux_params *p, uint32_t block_size)
 {
@@ -430,8 +434,7 @@ const char *redux_decode_kernel_name_n(const redux_params *p, const void *d_out,
     case DecKernel::Gen4: return "k_decode_gen<4> (4-bit symbols beyond 2^17 per block: per-level walk, u32 tree in LDS)";
     case DecKernel::Cells:
     case DecKernel::CellsWorkspace: {
-        // lock-step, the tree as cells of four levels: all of them in LDS, or (11- and 12-bit symbols on a grid that fills the
-        // chip: redux_decode_kernel_name answers for that grid) the bottom ones in the workspace
+        // lock-step, the tree as cells of four levels: all of them in LDS (symbol_bits <= 10), or the bottom ones in the workspace
         static const char *const names[13] = {"", "k_decode_cells<1>", "k_decode_cells<2>", "k_decode_cells<3>", "k_decode_cells<4>",
                                                "k_decode_cells<5>", "k_decode_cells<6>", "k_decode_cells<7>", "", "k_decode_cells<9>",
                                                "k_decode_cells<10>", "k_decode_cells<11>", "k_decode_cells<12>"};
@@ -839,7 +842,7 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
     if (check_params(p) != REDUX_OK || block_size == 0)
         return 0;
     const Geometry g = geometry(p, block_size, block_size);
-    if (g.gen) // (11- and 12-bit symbols on a large grid decode with their bottom cells in the workspace: gen_decode_in_workspace)
+    if (g.gen) // (11- and 12-bit symbols: the bottom cells of the decoder's tree live in the workspace: gen_decode_in_workspace)
         return align_up((uint64_t)g.rc_n * 8, 256) +
                (gen_decode_cells(p, block_size) && gen_decode_in_workspace(p, nblocks) ? (nblocks + 63) / 64 * 64 * gen_decode_tree_bytes(p) : 0);
     if (g.any)
@@ -893,17 +896,17 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
             // every tree starts at all-ones frequencies: a node = its lowbit
             const uint64_t npieces = (uint64_t)grid64 * 64 * gen_decode_tree_bytes(p) / 16;
             k_fill_cells16<<<(uint32_t)((npieces + 255) / 256), 256, 0, s>>>((cl_u32x4 *)ga.trees, npieces);
-            if (p->symbol_bits == 12)
-                k_decode_cells<12, 64, true><<<grid64, 64, 0, s>>>(ga);
-            else
+            if (p->symbol_bits == 11)
                 k_decode_cells<11, 64, true><<<grid64, 64, 0, s>>>(ga);
+            else
+                k_decode_cells<12, 64, true><<<grid64, 64, 0, s>>>(ga);
             break;
         }
         case DecKernel::Cells:
             switch (p->symbol_bits) {
 #define REDUX_GEN_DEC(SB, LANES) case SB: k_decode_cells<SB, LANES, false><<<(uint32_t)((nblocks + LANES - 1) / LANES), LANES, 0, s>>>(ga); break;
                 REDUX_GEN_DEC(1, 64) REDUX_GEN_DEC(2, 64) REDUX_GEN_DEC(3, 64) REDUX_GEN_DEC(4, 64) REDUX_GEN_DEC(5, 64) REDUX_GEN_DEC(6, 64)
-                REDUX_GEN_DEC(7, 64) REDUX_GEN_DEC(9, 64) REDUX_GEN_DEC(10, 64) REDUX_GEN_DEC(11, 32) REDUX_GEN_DEC(12, 16)
+                REDUX_GEN_DEC(7, 64) REDUX_GEN_DEC(9, 64) REDUX_GEN_DEC(10, 64)
 #undef REDUX_GEN_DEC
             default: return REDUX_UNSUPPORTED;
             }

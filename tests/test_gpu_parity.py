@@ -1282,7 +1282,7 @@ def test_gen_kernels_hand_large_blocks_to_the_one_lane_kernels(rx):
 
 
 def test_12_bit_decoder_on_a_large_grid_uses_workspace_trees(rx):
-    """16,384 blocks and more: k_decode_cells<12, 64, true> (bottom cells in the workspace, 64 blocks per wave) instead of the LDS form.
+    """A grid of more than one wave of 12-bit symbols: k_decode_cells<12, 64, true> (bottom cells in the workspace, 64 blocks per wave).
     Small blocks keep it quick: streams against the oracle on a sample, everything decoded back."""
     rng = np.random.default_rng(21)
     bs, nb = 96, 16400 + 37

@@ -16,7 +16,10 @@ nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 n = nb * BLOCK
 d_in = rx.gen_zipf(n)
 res = {}
-for params in ((4, 28, 32), (5, 27, 32), (12, 20, 32), (11, 21, 32)):
+PARAMS = ((4, 28, 32), (5, 27, 32), (12, 20, 32), (11, 21, 32))
+if len(sys.argv) > 2:  # tools/measure_gen.py <blocks> 9,23,32 10,22,32 ...
+    PARAMS = tuple(tuple(int(x) for x in a.split(",")) for a in sys.argv[2:])
+for params in PARAMS:
     enc = rx.DeviceEncoder(params, BLOCK, n)
     dec = rx.DeviceDecoder(params, BLOCK, nb)
     out, offs, st, sm = enc.encode(d_in)
