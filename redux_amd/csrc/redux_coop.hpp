@@ -269,9 +269,13 @@ __device__ __forceinline__ void emit_careful(EncState &S, uint32_t topk, uint32_
     }
 }
 
-template <bool CB32, bool FIXUP>
+// LINEAR: the launch has fewer than 64 (large) blocks and its slots are linear -- a lane's dwords contiguous in its own
+// slot, lanes without a block in the spare slot behind the last one -- instead of one row-major area of 64 slots: the
+// workspace of such a launch (ONE block of any length above all: redux_compress) then holds nblocks + 1 slots, not 65.
+template <bool CB32, bool FIXUP, bool LINEAR = false>
 __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pairs)
 {
+    constexpr int ST = LINEAR ? (4 | kSwapped) : kPairStride;
     __shared__ uint2 ring[kCoopRing / 8];
     __shared__ uint2 fin[64]; // (low after the EOF symbol, its shifts): what encode_finish needs from the chain
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -405,10 +409,10 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
     }
 
     // ---------------- emit wave ----------------
-    uint8_t       *wdst  = a.slots + (uint64_t)blockIdx.x * (64 * a.slot_bytes + 128);
-    const uint32_t off0  = lane * 4u;
-    const uint32_t limit = off0 + (a.slot_cap / 4u) * 256u;
-    constexpr uint32_t kChunkBudget = (16 * 4 + 32) * (stride_of<kPairStride> / 4);
+    uint8_t       *wdst  = LINEAR ? a.slots : a.slots + (uint64_t)blockIdx.x * (64 * a.slot_bytes + 128);
+    const uint32_t off0  = LINEAR ? (live ? lane : (uint32_t)a.nblocks) * (uint32_t)a.slot_bytes : lane * 4u;
+    const uint32_t limit = LINEAR ? off0 + (a.slot_cap & ~3u) : off0 + (a.slot_cap / 4u) * 256u;
+    constexpr uint32_t kChunkBudget = (16 * 4 + 32) * (stride_of<ST> / 4);
     EncState S;
     enc_init(S, off0);
     for (uint32_t t = 0; t < nperiods; t++) {
@@ -435,7 +439,7 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                     uint32_t       nbm = S.nb - 32u, mx = 0;
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
-                        const uint32_t m = emit_spec<kPairStride>(S, nbm, msg[8 * g + i].x, msg[8 * g + i].y, wdst);
+                        const uint32_t m = emit_spec<ST>(S, nbm, msg[8 * g + i].x, msg[8 * g + i].y, wdst);
                         mx = m > mx ? m : mx;
                     }
                     S.nb = nbm + 32u;
@@ -443,13 +447,13 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                         S = S0;
 #pragma unroll
                         for (int i = 0; i < 8; i++)
-                            emit_careful<kPairStride>(S, msg[8 * g + i].x, msg[8 * g + i].y, wdst, 0xFFFFFFFFu);
+                            emit_careful<ST>(S, msg[8 * g + i].x, msg[8 * g + i].y, wdst, 0xFFFFFFFFu);
                     }
                     const uint32_t pg = p + 8 * g;
                     if (pg + 8 > main_end && live && len >= pg && len < pg + 8) { // this lane's EOF symbol was among the eight
                         const uint2 f = fin[lane];
                         S.low         = f.x;
-                        const uint32_t size = encode_finish<kPairStride>(S, f.y, a.code_bits, off0, wdst, limit);
+                        const uint32_t size = encode_finish<ST>(S, f.y, a.code_bits, off0, wdst, limit);
                         a.sizes[EL.ob]  = size;
                         a.status[EL.ob] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
                     }
@@ -463,11 +467,11 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                         mg = i == (uint32_t)k ? msg[k] : mg;
                     const uint32_t q = p + i;
                     if (q < main_end || (live && q <= len)) // (below main_end dead lanes code their copy, in step with the chain wave)
-                        emit_careful<kPairStride>(S, mg.x, mg.y, wdst, limit);
+                        emit_careful<ST>(S, mg.x, mg.y, wdst, limit);
                     if (live && q == len) {
                         const uint2 f = fin[lane];
                         S.low         = f.x;
-                        const uint32_t size = encode_finish<kPairStride>(S, f.y, a.code_bits, off0, wdst, limit);
+                        const uint32_t size = encode_finish<ST>(S, f.y, a.code_bits, off0, wdst, limit);
                         a.sizes[EL.ob]  = size;
                         a.status[EL.ob] = size > a.slot_cap ? REDUX_OUTPUT_TOO_SMALL : REDUX_OK;
                     }

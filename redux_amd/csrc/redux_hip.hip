@@ -121,6 +121,7 @@ struct Geometry {
     bool     gen;        // ... except 4- and 12-bit symbols with code_bits <= 32: lock-step kernels of redux_gen.hpp
     uint64_t tree_bytes; // any / gen (12-bit symbols): per-block tree in the workspace
     bool     coop;       // small grid: k_coop_model + k_coop_chain (redux_coop.hpp), (low, high) pairs in the workspace
+    bool     coop_linear; // ... with fewer than 64 large blocks: linear slots, nblocks + 1 of them (k_coop_chain<.., LINEAR>)
     uint32_t pair_width; // ... in rows of this many lanes
     // workspace layout (encode)
     uint64_t off_rc, off_sizes, off_mode, off_slots, off_trees, off_table, off_seen, off_pairs, total;
@@ -210,7 +211,7 @@ static uint64_t slot_cap_for(const redux_params *p, uint32_t block_size)
 // static_model: the fixed-table coder (redux_static.hpp).  A symbol of frequency >= 1 out of
 // total <= freq_max costs at most freq_bits bits + 1 for the truncation of codec.rs:59-60, + 1
 // spare; no reciprocal table, no tree.
-static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_size, bool static_model = false)
+static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_size, bool static_model = false, bool allow_coop = true)
 {
     Geometry g;
     memset(&g, 0, sizeof g);
@@ -252,24 +253,40 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
         g.fixup      = true;
         g.tree_bytes = align_up(((1ull << p->symbol_bits) + 2) * 4, 256);
     }
-    g.off_rc    = 0;
-    g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
-    g.off_mode  = align_up(g.off_sizes + g.nblocks * 4, 256); // one word: 0 linear slots, != 0 row-major group areas
-    g.off_slots = g.off_mode + 256 + kClaimWords * 4; // mode word, then k_encode_pair's role book
-    // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode
-    g.off_trees = align_up(g.off_slots + ((g.nblocks + 63) / 64 * 64 + 1) * g.slot_bytes + (g.nblocks + 63) / 64 * 128, 256);
-    // the checked copy of a `_v_dev` call's block table + the bitmap of block numbers its check uses (redux_table.hpp)
-    g.off_table = align_up(g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes, 256); // gen: whole waves
-    g.off_seen  = g.off_table + align_up(g.nblocks * sizeof(redux_block), 256);
-    g.off_pairs = g.off_seen + align_up(table_seen_words(g.nblocks) * 4, 256);
     // a grid that leaves most SIMDs idle: the model by 64 lanes per block, the chain by one.  One block of any length --
     // redux_compress, the literal redux::compress -- is such a grid.  The pairs are rows of pair_width lanes (64, or the
     // number of blocks when there are fewer and they are large), block_size + slack rows per group of 64 blocks.
     g.pair_width = (g.nblocks < 64 && !g.u16) ? (uint32_t)g.nblocks : 64u; // (large blocks only: a constant row stride is faster to address)
     const uint64_t pair_bytes = (g.nblocks + 63) / 64 * g.pair_width * ((uint64_t)block_size + kCoopSlack) * 8;
-    g.coop = !static_model && !g.any && !g.gen && g.nblocks <= kCoopMaxBlocks && block_size >= kCoopMinBlock &&
+    g.coop = allow_coop && !static_model && !g.any && !g.gen && g.nblocks <= kCoopMaxBlocks && block_size >= kCoopMinBlock &&
              64ull * g.slot_bytes < (1ull << 32) && pair_bytes <= kCoopMaxPairBytes;
+    // fewer than 64 large blocks on the small-grid kernels: linear slots, one per block + a spare one for the lanes without
+    // a block (a row-major group area is 64 slots big whatever the number of blocks: 230 MiB to code one 3 MiB stream)
+    g.coop_linear = g.coop && g.nblocks < 64 && !g.u16;
+    g.off_rc    = 0;
+    g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
+    g.off_mode  = align_up(g.off_sizes + g.nblocks * 4, 256); // one word: 0 linear slots, != 0 row-major group areas
+    g.off_slots = g.off_mode + 256 + kClaimWords * 4; // mode word, then k_encode_pair's role book
+    // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode
+    const uint64_t nslots = g.coop_linear ? g.nblocks + 1 : (g.nblocks + 63) / 64 * 64 + 1;
+    g.off_trees = align_up(g.off_slots + nslots * g.slot_bytes + (g.nblocks + 63) / 64 * 128, 256);
+    // the checked copy of a `_v_dev` call's block table + the bitmap of block numbers its check uses (redux_table.hpp)
+    g.off_table = align_up(g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes, 256); // gen: whole waves
+    g.off_seen  = g.off_table + align_up(g.nblocks * sizeof(redux_block), 256);
+    g.off_pairs = g.off_seen + align_up(table_seen_words(g.nblocks) * 4, 256);
     g.total = g.off_pairs + (g.coop ? pair_bytes : 0);
+    return g;
+}
+
+// The layout a launch uses in the workspace it was GIVEN.  A workspace sized for a larger input, or for a pipeline of several
+// chunks, has no room for the small-grid kernels' pairs area: the launch then runs the full-grid kernels on the layout they
+// need (same bytes out, the small-launch speed-up forgone).  Both phases of a call -- the coder and the compaction -- must
+// take this decision the same way, so it is made here from (shape, workspace size) alone.
+static Geometry geometry_ws(const redux_params *p, uint64_t in_len, uint32_t block_size, uint64_t workspace_bytes)
+{
+    Geometry g = geometry(p, in_len, block_size);
+    if (g.coop && workspace_bytes < g.total)
+        g = geometry(p, in_len, block_size, false, false);
     return g;
 }
 
@@ -495,13 +512,9 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
         return st;
     if (block_size == 0 || !d_workspace || !d_block_status || (in_len && !d_in))
         return REDUX_INVALID_INPUT;
-    Geometry g = d_table ? geometry(p, tbl_blocks * (uint64_t)block_size, block_size) : geometry(p, in_len, block_size);
+    const Geometry g = geometry_ws(p, d_table ? tbl_blocks * (uint64_t)block_size : in_len, block_size, workspace_bytes);
     if (d_table && (g.gen || g.any || in_len > 0xFFFFFFFFull || tbl_blocks == 0)) // lane offsets into d_in are 32-bit
         return tbl_blocks == 0 ? REDUX_INVALID_INPUT : REDUX_UNSUPPORTED;
-    if (g.coop && workspace_bytes < g.total) { // a workspace sized for a larger input (which has no pairs area): the pair kernel
-        g.coop  = false;
-        g.total = g.off_pairs;
-    }
     if (workspace_bytes < g.total)
         return REDUX_OUTPUT_TOO_SMALL;
     if (((uintptr_t)d_workspace) & 255)
@@ -603,7 +616,7 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
     // what the pair kernel leaves in the slots (CompactArgs::mode): byte 0x01 -> row-major group
     // areas, 0x02 -> linear slots whose dwords are byte-reversed
     if (which == EncKernel::PairCb32 || which == EncKernel::Pair || which == EncKernel::CoopCb32 || which == EncKernel::Coop)
-        HIP_TRY(hipMemsetAsync(ws + g.off_mode, 1 | 2, 4, s));
+        HIP_TRY(hipMemsetAsync(ws + g.off_mode, g.coop_linear ? 2 : (1 | 2), 4, s));
     switch (which) {
     case EncKernel::CoopCb32:
     case EncKernel::Coop: {
@@ -614,7 +627,15 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
             k_coop_model<true><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
         else
             k_coop_model<false><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
-        if (g.fixup) {
+        if (g.coop_linear) {
+            if (g.fixup) {
+                if (cb32) k_coop_chain<true, true, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                else      k_coop_chain<false, true, true><<<cgrid, 128, 0, s>>>(a, pairs);
+            } else {
+                if (cb32) k_coop_chain<true, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                else      k_coop_chain<false, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
+            }
+        } else if (g.fixup) {
             if (cb32) k_coop_chain<true, true><<<cgrid, 128, 0, s>>>(a, pairs);
             else      k_coop_chain<false, true><<<cgrid, 128, 0, s>>>(a, pairs);
         } else {
@@ -696,7 +717,7 @@ int redux_compact_slots_dev(const redux_params *p, uint64_t in_len, uint32_t blo
         return st;
     if (block_size == 0)
         return REDUX_INVALID_INPUT;
-    return compact_with(geometry(p, in_len, block_size), d_out, out_cap, d_out_offsets, d_block_status, d_summary,
+    return compact_with(geometry_ws(p, in_len, block_size, workspace_bytes), d_out, out_cap, d_out_offsets, d_block_status, d_summary,
                         d_workspace, workspace_bytes, stream);
 }
 
@@ -725,7 +746,7 @@ int redux_encode_blocks_v_dev(const redux_params *p, const void *d_in, uint64_t 
     if (st != REDUX_OK)
         return st;
     // (from here on the table is its checked copy in the workspace)
-    const Geometry g = geometry(p, nentries * (uint64_t)block_size, block_size);
+    const Geometry g = geometry_ws(p, nentries * (uint64_t)block_size, block_size, workspace_bytes);
     st = compact_with(g, d_out, out_cap, d_out_offsets, d_block_status, d_summary, d_workspace, workspace_bytes, stream,
                       (const redux_block *)((uint8_t *)d_workspace + g.off_table), nblocks);
     if (st != REDUX_OK)

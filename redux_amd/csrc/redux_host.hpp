@@ -635,7 +635,7 @@ static int encode_blocks(const redux_params *p, const uint8_t *in, uint64_t in_l
     E.chunk_in = E.cb * (uint64_t)block_size; // bytes of a full chunk
     E.ws_bytes = redux_encode_workspace_bytes(p, E.chunk_in < in_len ? E.chunk_in : in_len, block_size);
     if (E.nchunks > 1) // several chunks in flight keep the chip busy: no pairs area, so the chunks run on the pair kernel (encode_slots_impl)
-        E.ws_bytes = geometry(p, E.chunk_in, block_size).off_pairs;
+        E.ws_bytes = geometry(p, E.chunk_in, block_size, false, false).total;
     E.bound    = redux_encode_bound(p, E.chunk_in < in_len ? E.chunk_in : in_len, block_size);
     Job J;
     J.total.assign(E.nchunks, 0);

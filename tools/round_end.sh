@@ -13,11 +13,15 @@ cp $(ls -t gpurun_out/prof_$TAG/trace/*/*kernel_stats.csv | head -1) $OUT/kernel
 # the bench lines last: they borrow the figures the passes above just wrote (same library, same source hash)
 timeout -k 10 300 python bench.py --steps 10 --warmup 10 > $OUT/bench_iid.log 2>&1 && tail -1 $OUT/bench_iid.log
 timeout -k 10 300 python bench.py --steps 10 --warmup 10 --workload zipf --no-cpu-baseline > $OUT/bench_zipf.log 2>&1 && tail -1 $OUT/bench_zipf.log
+timeout -k 10 300 python bench.py --workload file > $OUT/bench_file.log 2>&1 && tail -1 $OUT/bench_file.log
 timeout -k 10 300 python tools/measure_extra.py > $OUT/extra.log 2>&1 && tail -1 $OUT/extra.log
 # side measurements of the round: small launches, the other symbol widths, the static model, the corpus as one batch
 timeout -k 10 300 python tools/small_grid.py > $OUT/small_grid.txt 2>&1; tail -3 $OUT/small_grid.txt
 timeout -k 10 300 bash tools/prof_small.sh $TAG > $OUT/prof_small.txt 2>&1
-for nb in 4096 65536; do timeout -k 10 400 python tools/measure_gen.py $nb >> $OUT/gen.txt 2>&1; done; tail -2 $OUT/gen.txt
+for nb in 4096 16384 65536; do timeout -k 10 400 python tools/measure_gen.py $nb >> $OUT/gen.txt 2>&1; done; tail -3 $OUT/gen.txt
+timeout -k 10 400 python tools/measure_gen.py 65536 1,10,16 2,10,16 4,10,16 6,26,32 7,25,32 9,23,32 10,22,32 12,14,16 >> $OUT/gen.txt 2>&1; tail -1 $OUT/gen.txt
+timeout -k 10 300 python tools/measure_wave.py > $OUT/wave.txt 2>&1; tail -2 $OUT/wave.txt
+timeout -k 10 300 python tools/soak_cells.py 150 41 > $OUT/soak.txt 2>&1; tail -1 $OUT/soak.txt
 timeout -k 10 300 python tools/measure_static.py >> $OUT/static.txt 2>&1; tail -1 $OUT/static.txt
 timeout -k 10 500 python tools/corpus_table.py --batch > $OUT/corpus_batch.txt 2>&1
 timeout -k 10 500 python tools/corpus_table.py --batch --corpora calgary,canterbury >> $OUT/corpus_batch.txt 2>&1
