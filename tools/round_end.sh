@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round-end measurement batch (GPU box): parity tests, bench lines, side measurements, rocprofv3 summaries.
-# Usage: tools/round_end.sh <tag>   -> gpurun_out/final_<tag>/... and gpurun_out/profiles_json/{traffic,issue}.json
-TAG=${1:-x}; OUT=gpurun_out/final_$TAG; mkdir -p $OUT
+# Usage: tools/round_end.sh <tag> [a|b]   -> gpurun_out/final_<tag>/... and gpurun_out/profiles_json/{traffic,issue}.json
+# (the whole batch no longer fits one 20-minute gpurun call: part a = tests, profiles, bench lines; part b = side measurements)
+TAG=${1:-x}; PART=${2:-ab}; OUT=gpurun_out/final_$TAG; mkdir -p $OUT
+if [[ $PART == *a* ]]; then
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/tests_gpu.log 2>&1; tail -2 $OUT/tests_gpu.log
 timeout -k 10 600 bash tools/prof.sh $TAG > $OUT/prof.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/prof_$TAG k_encode_pair > $OUT/prof_summary.txt 2>&1
@@ -14,6 +16,8 @@ cp $(ls -t gpurun_out/prof_$TAG/trace/*/*kernel_stats.csv | head -1) $OUT/kernel
 timeout -k 10 300 python bench.py --steps 10 --warmup 10 > $OUT/bench_iid.log 2>&1 && tail -1 $OUT/bench_iid.log
 timeout -k 10 300 python bench.py --steps 10 --warmup 10 --workload zipf --no-cpu-baseline > $OUT/bench_zipf.log 2>&1 && tail -1 $OUT/bench_zipf.log
 timeout -k 10 300 python bench.py --workload file > $OUT/bench_file.log 2>&1 && tail -1 $OUT/bench_file.log
+fi
+if [[ $PART == *b* ]]; then
 timeout -k 10 300 python tools/measure_extra.py > $OUT/extra.log 2>&1 && tail -1 $OUT/extra.log
 # side measurements of the round: small launches, the other symbol widths, the static model, the corpus as one batch
 timeout -k 10 300 python tools/small_grid.py > $OUT/small_grid.txt 2>&1; tail -3 $OUT/small_grid.txt
@@ -25,4 +29,5 @@ timeout -k 10 300 python tools/soak_cells.py 150 41 > $OUT/soak.txt 2>&1; tail -
 timeout -k 10 300 python tools/measure_static.py >> $OUT/static.txt 2>&1; tail -1 $OUT/static.txt
 timeout -k 10 500 python tools/corpus_table.py --batch > $OUT/corpus_batch.txt 2>&1
 timeout -k 10 500 python tools/corpus_table.py --batch --corpora calgary,canterbury >> $OUT/corpus_batch.txt 2>&1
+fi
 echo done
