@@ -5,7 +5,7 @@
 // decompress_stream (codec.rs:164-176) of LANES blocks per wave, one lane per block, all lanes on the same symbol index, so
 // the model's total -- 2^symbol_bits + 1 + symbols decoded, until the freq_max freeze (adaptive_tree.rs:84) -- is
 // wave-uniform and the divisions of codec.rs:131-134 are multiplications by reciprocals.  What is new against the
-// per-level walk of k_decode_gen (symbol_bits DEPENDENT probes per symbol):
+// per-level walk of rounds 2 and 3 (k_decode_gen: symbol_bits DEPENDENT probes per symbol):
 //
 //   * the Fenwick tree of adaptive_tree.rs:36-48 as CELLS of four levels.  Group g (g = 0: levels 3..0, g = 1: levels
 //     7..4, g = 2: levels 11..8) holds one cell per prefix of the symbol bits above it; a cell is the fifteen nodes
@@ -39,7 +39,7 @@
 //     dwords at static bit positions (write_bits(symbol, symbol_bits) MSB-first, bitio/mod.rs:148-181).
 //   * the lock-step loop runs while every step has room for its symbol, the count stays below 2^17 (no quotient fix-up,
 //     scale_div) and the output is 4-byte aligned; the last < U symbols, the EOF symbol, a symbol that does not fit
-//     (OutputTooSmall is decided byte by byte, codec.rs:171) are k_decode_gen's per-lane loop over the same cells.
+//     (OutputTooSmall is decided byte by byte, codec.rs:171) are a per-lane loop over the same cells, one probe per level.
 //
 // Included by redux_hip.hip (one translation unit).
 #pragma once
@@ -256,9 +256,15 @@ struct CellTree {
     }
 };
 
-template <int SB, int LANES, bool GLOBAL0>
+// FIX (u32 nodes only): the count may pass 2^17 inside a block -- symbol widths <= 7 in blocks of more than 2^17 symbols with
+// a model that does not freeze below that.  The code value is then the quotient of a numerator of up to 62 bits: estimated
+// with a Newton-refined reciprocal and settled by the exact 64-bit remainder (as k_decode_wave's), the two ends of the new
+// interval take scale_div's fix-up, and the interval may collapse to low == high (k = 32: 64-bit shifts).  ~25 more
+// instructions per step; without it such blocks ran on the one-lane kernels.
+template <int SB, int LANES, bool GLOBAL0, bool FIX = false>
 __global__ void __launch_bounds__(64) k_decode_cells(GenDecArgs a)
 {
+    static_assert(!FIX || SB < 8, "the fix-up variant is for the u32-node widths");
     typedef CellGeom<SB, LANES, GLOBAL0> G;
     __shared__ __attribute__((aligned(16))) uint32_t lds[G::kLdsBytes / 4];
     // One wave per SIMD, by construction ("placement"): a lock-step wave that shares its SIMD takes
@@ -361,7 +367,7 @@ __global__ void __launch_bounds__(64) k_decode_cells(GenDecArgs a)
     // ---------------- lock-step turns of kSteps symbols ----------------
     const uint32_t pend    = (uint32_t)(((uint64_t)capn * 8) / SB);          // symbols a block has room for
     const uint32_t pnofix  = (1u << 17) - kCount0;                          // count < 2^17 while p < pnofix, or for good if it freezes below
-    const uint32_t pfast   = (nfreeze < pnofix || pend < pnofix) ? pend : pnofix;
+    const uint32_t pfast   = (FIX || nfreeze < pnofix || pend < pnofix) ? pend : pnofix;
     const bool     aligned = (((uintptr_t)a.out | a.block_size) & 3u) == 0;
     if (aligned) {
         typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -379,6 +385,8 @@ __global__ void __launch_bounds__(64) k_decode_cells(GenDecArgs a)
         uint32_t fin_cons = consumed;
         uint32_t R1  = r1 >> sh;
         double   R1d = (double)R1, xd = R1d + 1.0, rinv = __builtin_amdgcn_rcp(xd);
+        if (FIX)
+            rinv = __builtin_fma(__builtin_fma(-xd, rinv, 1.0), rinv, rinv);
         for (; p + G::kSteps <= pfast; p += G::kSteps) {
             if (__builtin_amdgcn_ballot_w64((int32_t)dflag >= 0) == 0)
                 break;
@@ -415,12 +423,20 @@ __global__ void __launch_bounds__(64) k_decode_cells(GenDecArgs a)
                     }
                     // ---- code value (codec.rs:129-131): dec_value() with the reciprocal of the range already at hand
                     const uint32_t Vd  = (W - low) >> sh;
-                    const double   nd  = __builtin_fma((double)Vd, cd, cdm1); // (Vd+1)*c - 1, exact (< 2^49)
-                    const uint32_t v0p = (uint32_t)__builtin_fma(nd, rinv, -0x1p-6) + 1u;
-                    const double   rem = __builtin_fma(-(double)v0p, xd, nd);
-                    uint32_t fix = (uint32_t)((int32_t)(uint32_t)((uint64_t)__double_as_longlong(rem) >> 32) >> 31); // -1: v0p is one too many
-                    asm("" : "+v"(fix));
-                    const uint32_t v = v0p + fix;
+                    uint32_t       v;
+                    if (FIX) {
+                        const uint64_t num = (uint64_t)Vd * c + (c - 1u); // (Vd+1)*c - 1: up to 62 bits
+                        v                  = (uint32_t)((double)num * rinv);
+                        const int64_t r    = (int64_t)(num - ((uint64_t)v * R1 + v));
+                        v += r < 0 ? 0xFFFFFFFFu : ((uint64_t)r > (uint64_t)R1 ? 1u : 0u);
+                    } else {
+                        const double   nd  = __builtin_fma((double)Vd, cd, cdm1); // (Vd+1)*c - 1, exact (< 2^49)
+                        const uint32_t v0p = (uint32_t)__builtin_fma(nd, rinv, -0x1p-6) + 1u;
+                        const double   rem = __builtin_fma(-(double)v0p, xd, nd);
+                        uint32_t fix = (uint32_t)((int32_t)(uint32_t)((uint64_t)__double_as_longlong(rem) >> 32) >> 31); // -1: v0p is one too many
+                        asm("" : "+v"(fix));
+                        v = v0p + fix;
+                    }
                     // ---- get_symbol (adaptive_tree.rs:115-136), a cell per four levels, topmost first
                     CellDescent D;
                     D.q    = ~v;
@@ -476,14 +492,16 @@ __global__ void __launch_bounds__(64) k_decode_cells(GenDecArgs a)
                     const uint32_t lo  = v + D.q + 1u;  // v - rem = cum(s)
                     const uint32_t hi  = v + D.hq + 1u; // cum(s + 1): the upper boundary of the last level that went left
                     // ---- narrowing and renormalisation (codec.rs:133-161), closed form as k_decode_lock
-                    const uint32_t nlow   = low + (scale_div<false>(R1, Y, lo, c) << sh);
-                    const uint32_t nihigh = 0u - (low + (scale_div<false, true>(R1, Y, hi, c) << sh));
+                    const uint32_t nlow   = low + (scale_div<FIX>(R1, Y, lo, c) << sh);
+                    const uint32_t nihigh = 0u - (low + (scale_div<FIX, true>(R1, Y, hi, c) << sh));
                     const uint32_t xx     = ~(nlow ^ nihigh);
                     uint32_t       k;
                     asm("v_ffbh_u32 %0, %1" : "=v"(k) : "v"(xx)); // (32-bit codes: low != high while count < 2^17; narrower ones:
                                                                   // the padding below the code differs, so k <= code_bits)
-                    const uint32_t low2  = nlow << (k & 31u);
-                    const uint32_t ih2   = nihigh << (k & 31u);
+                    if (FIX)
+                        k = k < 32u ? k : 32u; // (low == high: v_ffbh's -1; all 32 bits are shared and shift out)
+                    const uint32_t low2  = FIX ? (uint32_t)((uint64_t)nlow << k) : nlow << (k & 31u);
+                    const uint32_t ih2   = FIX ? (uint32_t)((uint64_t)nihigh << k) : nihigh << (k & 31u);
                     const uint32_t t2    = (low2 & ih2) << 1;
                     const uint32_t j     = (uint32_t)__builtin_clz(~t2);
                     const uint32_t n     = k + j; // bits pulled by get_bit (codec.rs:157)
@@ -505,6 +523,8 @@ __global__ void __launch_bounds__(64) k_decode_cells(GenDecArgs a)
                     R1d  = (double)R1;
                     xd   = R1d + 1.0;
                     rinv = __builtin_amdgcn_rcp(xd);
+                    if (FIX)
+                        rinv = __builtin_fma(__builtin_fma(-xd, rinv, 1.0), rinv, rinv);
                     // ---- the two ways a block ends here
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64((int32_t)e < 0) != 0, 0)) { // one scalar branch; selects inside
                         const bool fin        = (int32_t)e < 0;
@@ -542,7 +562,8 @@ __global__ void __launch_bounds__(64) k_decode_cells(GenDecArgs a)
     }
 
     // ---------------- per-lane steps: the last symbols of a block, the EOF symbol, unaligned output ----------------
-    // k_decode_gen's loop (redux_gen.hpp) over the same cells; the bit reader restarts at the consumed-bit count.
+    // decompress_symbol statement by statement, one probe per level over the same cells; the bit reader restarts at the
+    // consumed-bit count.
     bool     done  = (int32_t)dflag < 0;
     uint32_t high  = ~((~r1 - low) & 0x7FFFFFFFu);
     uint64_t obits = (uint64_t)(done ? n_out : p) * SB; // bits handed to write_bits so far: bytes [0, obits / 8) are in dst

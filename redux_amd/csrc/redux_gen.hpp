@@ -1,26 +1,25 @@
-// redux_gen.hpp -- the lock-step block coder for the OTHER symbol widths the reference tests
-// (src/model/tests.rs:95-251: 4- and 12-bit symbols), code_bits <= 32 (gfx950 only).  SURVEY section 8(f).3.
+// redux_gen.hpp -- the lock-step ENCODERS for the symbol widths other than 8 (symbol_bits 1 .. 12, code_bits <= 32; gfx950
+// only): the widths src/model/tests.rs:95-251 exercises (4 and 12) and everything between.  SURVEY section 8(f).3.  Their
+// decoder is k_decode_cells (redux_decode_cells.hpp).
 //
-// redux_any.hpp covers every Parameters triple as a one-lane-per-block rendering of the reference's loops.  For
-// symbol_bits 4 and 12 this file is the MI355X form of the same functions, built like the 8-bit kernels:
-//   * one LANE per block, 64 blocks per wave, all lanes on the same symbol index, so the model's total
-//     (2^symbol_bits + 1 + symbols coded, until the freq_max freeze: adaptive_tree.rs:84) is WAVE-UNIFORM and the two
-//     u64 divisions of codec.rs:59-60 are multiplications by a per-step reciprocal (scale_div<FIXUP = true>: a block
-//     of 4-bit symbols passes count 2^17);
+// redux_any.hpp covers every Parameters triple as a one-lane-per-block rendering of the reference's loops.  This file is
+// the MI355X form of compress_stream for these widths, built like the 8-bit kernels:
+//   * one LANE per block, all lanes on the same symbol index, so the model's total (2^symbol_bits + 1 + symbols coded,
+//     until the freq_max freeze: adaptive_tree.rs:84) is WAVE-UNIFORM and the two u64 divisions of codec.rs:59-60 are
+//     multiplications by a per-step reciprocal (scale_div; with its quotient fix-up once the count can pass 2^17);
 //   * the Fenwick tree as increments d[i] = tree[i] - lowbit(i), i = 1 .. 2^symbol_bits - 1, in LDS, in per-lane
-//     columns.  4-bit symbols: u32, row e of lane l at e * 256 + 4 l: 16 rows = 4 KiB per wave of 64 blocks.  12-bit
-//     symbols: 4096 nodes per block, so the LDS, not the wave width, sets how many blocks a CU holds: u16 nodes (blocks of
-//     at most 65535 symbols = 98,302 bytes; longer ones run on the one-lane kernels), two lanes to a dword, SIXTEEN live
-//     lanes per wave: 128 KiB, one workgroup per CU.  (Round 2 kept 64 trees of 1 MiB per wave in the workspace and walked them with global
-//     fetch-adds: 6.6 GB/s on the full grid, the atomics going to HBM.)
+//     columns.  symbol_bits <= 7: u32, row e of lane l at e * 256 + 4 l (4-bit: 4 KiB per wave of 64 blocks).  symbol_bits
+//     >= 9: the LDS, not the wave width, sets how many blocks a CU holds: u16 nodes (at most 65535 updates of the model),
+//     two lanes to a dword, 64 / 64 / 32 / 16 blocks per workgroup for 9 / 10 / 11 / 12 bits (128 KiB for 12: one
+//     workgroup per CU), coded by FOUR waves (k_encode_gen_pair);
 //   * get_frequency = one fetch-add per level (addend 1 where update(s+1) increments the node, 0 where the prefix
 //     sums only read it) + two masked sums (adaptive_tree.rs:63-92), closed-form renormalisation and bit output
-//     exactly as encode_symbol (redux_coder.hpp); the decoder's descent probes the same nodes (adaptive_tree.rs:115-136);
-//   * symbols are read_bits(symbol_bits) MSB-first (bitio/mod.rs:78-120): two per byte, or two per three bytes; a
-//     trailing partial symbol is dropped and the block ends (Err(Eof) -> EOF symbol, codec.rs:108); the decoder writes
-//     write_bits(symbol, symbol_bits) and never flushes a partial byte (lib.rs:113-120).
-// Everything is predicated per lane (ragged blocks, errors): this path is about being a designed kernel instead of a
-// port, not about the last instruction; the 8-bit kernels are the tuned ones.
+//     exactly as encode_symbol (redux_coder.hpp);
+//   * symbols are read_bits(symbol_bits) MSB-first (bitio/mod.rs:78-120); a trailing partial symbol is dropped and the
+//     block ends (Err(Eof) -> EOF symbol, codec.rs:108);
+//   * whole waves run unpredicated: k_encode_gen in turns of 32 symbols (= symbol_bits dwords of input, loaded a turn
+//     ahead), k_encode_gen_pair's coder wave in halves of eight, its model waves on a half's symbol_bits bytes loaded as
+//     dwords a half ahead; ragged waves, the last symbols of a block and the EOF symbol take per-lane predicated loops.
 //
 // Included by redux_hip.hip (one translation unit).
 #pragma once
@@ -35,11 +34,8 @@
 
 namespace redux {
 
-// INLDS (always for 4-bit symbols): the trees of a wave's blocks in LDS.  !INLDS (12-bit symbols, large grids, decode):
-// 64 trees of u32 per wave in the workspace, 1 MiB, walked with global loads and fetch-adds -- slower per step, but
-// 64 blocks per wave and several waves per SIMD instead of 16 blocks per CU: on the full grid the decoder, whose
-// descent is twelve DEPENDENT probes, is faster this way (6.5 against 4.2 GB/s), the encoder, whose twelve fetch-adds
-// are independent, in LDS (8.6 against 6.6 GB/s); below ~16,384 blocks both are 3 x faster in LDS.
+// The trees of a wave's blocks in LDS (INLDS; the other form -- u32 trees in the workspace, walked with global fetch-adds --
+// served round 3's per-level decoder and is kept for experiments only).
 template <int SB, bool INLDS = true>
 struct GenTree {
     static constexpr bool     kU16    = INLDS && SB > 8;    // u16 nodes, lanes l and l + kBlocks / 2 in one dword
@@ -227,8 +223,8 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
         constexpr uint32_t U = 32;
         const bool     whole  = __builtin_amdgcn_ballot_w64(live) == ~0ull;
         const uint32_t minsym = __builtin_amdgcn_readfirstlane(wave_min(live ? nsym : 0u));
-        constexpr uint32_t kNoFix = (1u << 17) - kCount0;
-        const uint32_t e      = (nfreeze < kNoFix || minsym < kNoFix) ? minsym : kNoFix; // (a model that freezes below 2^17 never needs the fix-up)
+        constexpr uint32_t kNoFix = (1u << 17) - kCount0; // count < 2^17 while p < kNoFix, or for good if the model freezes below
+        const uint32_t e      = minsym;
         const uint32_t fast_end = (whole && (((uintptr_t)a.in | a.block_size) & 3u) == 0) ? (e & ~(U - 1u)) : 0u;
         if (fast_end) {
             constexpr uint32_t kBudget = U * 4 + 32; // bytes a turn may add on the common path (one dword per symbol at most) + slack
@@ -239,8 +235,8 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
                 cur[d] = wp[d];
             // (the loop exists twice: while every symbol of a turn updates the model -- count and reciprocal by induction --, and
             // with both selected per symbol for the turns from the freeze point on)
-            auto turns = [&](auto frozen_tag, const uint32_t pend) {
-            constexpr bool FRZ = decltype(frozen_tag)::value;
+            auto turns = [&](auto frozen_tag, auto fix_tag, const uint32_t pend) {
+            constexpr bool FRZ = decltype(frozen_tag)::value, FIX = decltype(fix_tag)::value; // FIX: the count may be 2^17 or more (scale_div's fix-up)
             for (; p < pend; p += U) {
                 if (__builtin_amdgcn_ballot_w64(S.off + kBudget > limit))
                     break; // a slot is nearly full: the checked loop below finishes the block
@@ -273,7 +269,7 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
                         const uint32_t nup = FRZ ? (p + k < nfreeze ? p + k : nfreeze) : p + k; // wave-uniform; past the freeze point nothing updates
                         uint32_t       lo, hi;
                         T.get_frequency(sym, nup, FRZ ? p + k < nfreeze : true, lo, hi);
-                        encode_symbol_fast<false>(S, lo, hi, kCount0 + nup, r[i], sh, wdst);
+                        encode_symbol_fast<FIX>(S, lo, hi, kCount0 + nup, r[i], sh, wdst);
                     }
                 }
 #pragma unroll
@@ -281,10 +277,15 @@ __global__ void __launch_bounds__(64) k_encode_gen(GenEncArgs a)
                     cur[d] = nxt[d];
             }
             };
+            // adaptive turns below 2^17, adaptive turns beyond (a block of more than 2^17 symbols whose model has not frozen),
+            // then the turns from the freeze point on
             const uint32_t a_end = fast_end < (nfreeze & ~(U - 1u)) ? fast_end : (nfreeze & ~(U - 1u));
-            turns(std::false_type(), a_end);
-            if (p == a_end && a_end < fast_end) // (not left early for a full slot)
-                turns(std::true_type(), fast_end);
+            const uint32_t n_end = a_end < (kNoFix & ~(U - 1u)) ? a_end : (kNoFix & ~(U - 1u));
+            turns(std::false_type(), std::false_type(), n_end);
+            if (p == n_end && n_end < a_end) // (not left early for a full slot)
+                turns(std::false_type(), std::true_type(), a_end);
+            if (p == a_end && a_end < fast_end && nfreeze < kNoFix) // (a model frozen at 2^17 or more: the loop below)
+                turns(std::true_type(), std::false_type(), fast_end);
         }
     }
 
@@ -509,167 +510,13 @@ struct GenDecArgs {
     uint32_t       *out_sizes;
     int32_t        *status;
     const double   *rc;
-    uint32_t       *trees;      // !INLDS: kRows * 64 u32 per wave, zero at launch
+    uint32_t       *trees;      // k_decode_cells<.., GLOBAL0>: the blocks' bottom cells (k_fill_cells16)
     uint64_t       *in_used;    // optional
     uint32_t        block_size;
     uint32_t        nfreeze;
     uint32_t        code_bits;
 };
 
-template <int SB, bool INLDS = true>
-__global__ void __launch_bounds__(64) k_decode_gen(GenDecArgs a)
-{
-    typedef GenTree<SB, INLDS> Tree;
-    __shared__ uint32_t lds[Tree::kLdsDwords];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t blk  = (uint64_t)blockIdx.x * Tree::kBlocks + lane;
-    const bool     live = lane < Tree::kBlocks && blk < a.nblocks;
-    if (INLDS) {
-        for (uint32_t i = lane; i < Tree::kLdsDwords / 4; i += 64)
-            reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
-    }
-    Tree T;
-    T.init(INLDS ? lds : a.trees + (uint64_t)blockIdx.x * Tree::kDwords, lane);
-
-    const uint32_t cb = a.code_bits, sh = 32 - cb;
-    uint64_t       size = 0;
-    const uint8_t *sp   = a.in;
-    if (live) {
-        const uint64_t o0 = a.in_offsets[blk];
-        size              = a.in_offsets[blk + 1] - o0;
-        sp                = a.in + o0;
-    }
-    const uint64_t stream_bits = size * 8;
-    uint8_t       *dst         = a.out + (live ? blk : 0) * (uint64_t)a.block_size;
-    const uint32_t capn        = a.block_size; // bytes
-    const rc_ptr   rcp         = (rc_ptr)a.rc;
-    constexpr uint32_t kCount0 = (1u << SB) + 1u;
-
-    BitIn B;
-    B.init(sp, live ? size : 0);
-    uint32_t W        = B.take(cb) << sh; // codec.rs:124-127
-    uint64_t consumed = cb;
-    uint32_t low = 0, high = 0xFFFFFFFFu;
-    int32_t  st   = REDUX_OK;
-    bool     done = !live;
-    if (live && consumed > stream_bits) {
-        st   = REDUX_EOF;
-        done = true;
-    }
-    uint64_t obits = 0; // bits handed to write_bits so far (bitio/mod.rs:148-181): bytes [0, obits / 8) are in dst
-    uint32_t oacc  = 0; // the incomplete byte's bits, right-aligned
-    for (uint32_t p = 0;; p++) {
-        if (__builtin_amdgcn_readfirstlane(__ballot(!done) == 0))
-            break;
-        const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
-        const double   rc  = rcp[nup];
-        const uint32_t c   = kCount0 + nup;
-        if (!done) {
-            // value = ((pending - low + 1) * count - 1) / range      (codec.rs:129-131)
-            const uint32_t R1  = (high - low) >> sh;
-            const uint32_t Vd  = (W - low) >> sh;
-            const uint64_t num = ((uint64_t)Vd + 1) * c - 1;
-            const double   xd  = (double)R1 + 1.0;
-            uint32_t       v   = (uint32_t)((double)num / xd);
-            {
-                const int64_t r = (int64_t)(num - ((uint64_t)v * R1 + v));
-                if (r < 0)
-                    v--;
-                else if ((uint64_t)r > (uint64_t)R1)
-                    v++;
-            }
-            uint32_t lo, hi, s = 0;
-            bool     is_eof = false;
-            if (v >= c - 1) { // first probe of get_symbol: tree[2^SB] = 2^SB + #updates = count - 1 (adaptive_tree.rs:116)
-                is_eof = true;
-                lo     = c - 1;
-                hi     = c;
-            } else {
-                uint32_t x[SB], ea[SB];
-                uint32_t i = 0, rem = v;
-#pragma unroll
-                for (int b = SB - 1; b >= 0; b--) {
-                    ea[b] = i | (1u << b);
-                    x[b]  = T.load(ea[b]);
-                    const uint32_t tv = (1u << b) + x[b];
-                    if (rem >= tv) {
-                        i |= 1u << b;
-                        rem -= tv;
-                    }
-                }
-                s  = i;
-                lo = v - rem;
-                const uint32_t m  = s + 1;
-                uint32_t       hs = m;
-#pragma unroll
-                for (int b = 0; b < SB; b++)
-                    hs += ((m >> b) & 1u) ? x[b] : 0u;
-                hi = hs + (s == Tree::kMask ? nup : 0u);
-                if (p < a.nfreeze) {
-#pragma unroll
-                    for (int b = 0; b < SB; b++)
-                        if (!((s >> b) & 1u))
-                            T.fetch_add(ea[b], 1u);
-                }
-            }
-            if (is_eof) { // codec.rs:136-138: returns before any renormalisation
-                done = true;
-            } else {
-                const double   Y     = __builtin_fma((double)R1, rc, rc);
-                const uint32_t nlow  = low + (scale_div<true>(R1, Y, lo, c) << sh);
-                const uint32_t nhigh = low + (scale_div<true, true>(R1, Y, hi, c) << sh) - 1u;
-                const uint32_t xx    = nlow ^ nhigh;
-                const uint32_t k     = xx ? (uint32_t)__builtin_clz(xx) : 32u;
-                const uint32_t low2  = (uint32_t)((uint64_t)nlow << k);
-                const uint32_t ih2   = (uint32_t)((uint64_t)(~nhigh) << k);
-                const uint32_t t     = (low2 & ih2) << 1;
-                const uint32_t j     = (uint32_t)__builtin_clz(~t);
-                low                  = (low2 << j) & 0x7FFFFFFFu;
-                high                 = ~((ih2 << j) & 0x7FFFFFFFu);
-                const uint32_t n     = k + j; // bits pulled by get_bit (codec.rs:157)
-                consumed += n;
-                if (consumed > stream_bits) { // read_bits would hit Err(Eof) (bitio/mod.rs:107)
-                    st   = REDUX_EOF;
-                    done = true;
-                } else {
-                    const uint32_t nb   = B.take(n);
-                    const uint64_t comb = ((uint64_t)W << 32) | ((uint64_t)nb << (32 + sh - n));
-                    const uint64_t c1   = comb << k;
-                    const uint64_t c2   = c1 << j;
-                    W = (((uint32_t)(c2 >> 32) & 0x7FFFFFFFu) | ((uint32_t)(c1 >> 32) & 0x80000000u)) &
-                        (0xFFFFFFFFu << sh);
-                    // write_bits(symbol, SB) (codec.rs:171): bytes leave as they complete; the first one past the
-                    // block's capacity is where the writer fails
-                    uint32_t acc  = (oacc << SB) | s;
-                    uint32_t have = (uint32_t)(obits & 7u) + SB;
-                    uint64_t pos  = obits >> 3;
-                    while (have >= 8 && !done) {
-                        if (pos >= capn) {
-                            st   = REDUX_OUTPUT_TOO_SMALL;
-                            done = true;
-                        } else {
-                            have -= 8;
-                            dst[pos++] = (uint8_t)(acc >> have);
-                        }
-                    }
-                    if (!done) {
-                        oacc = acc & ((1u << have) - 1u);
-                        obits += SB;
-                    } else
-                        obits = pos * 8; // the bytes before the failing one are written
-                }
-            }
-        }
-    }
-    if (live) {
-        a.out_sizes[blk] = (uint32_t)(obits >> 3); // a partial byte is never flushed (lib.rs:113-120)
-        a.status[blk]    = st;
-        if (a.in_used) { // the reader fetches whole bytes, and never past the end of the stream
-            const uint64_t used = (consumed + 7) / 8;
-            a.in_used[blk]      = used < size ? used : size;
-        }
-    }
-}
+// (the decoder of these widths is k_decode_cells, redux_decode_cells.hpp; rounds 2 and 3 had a per-level walk here, k_decode_gen)
 
 } // namespace redux

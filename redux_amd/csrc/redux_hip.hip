@@ -147,10 +147,8 @@ static bool is_any(const redux_params *p) { return p->symbol_bits != 8 || p->cod
 //   * 4 MiB: the kernels index a reciprocal table by the symbol number and address 64 slots / 64 blocks with 32-bit lane offsets;
 //   * symbol_bits >= 9: u16 tree nodes holding lowbit + increments: at most 65535 - 2^(symbol_bits - 1) updates of the model
 //     (symbols of a block, or fewer if the model freezes first: 12-bit symbols, 20 frequency bits: blocks of 95,230 bytes);
-//   * symbol_bits <= 7: the decoder's lock-step loop runs while the count is below 2^17 (no quotient fix-up): a model that
-//     freezes below that, or blocks of at most 2^17 + 64 - (2^symbol_bits + 1) symbols -- what a 64 KiB block of 4-bit
-//     symbols has;
-//   * 4-bit symbols beyond that: k_encode_gen<4> and the per-level decoder k_decode_gen<4>.
+//   * symbol_bits <= 7: u32 nodes: any block up to the 4 MiB above; a block whose count can pass 2^17 takes the kernels'
+//     fix-up instances (quotient fix-ups in scale_div, a 62-bit numerator for the decoder's code value).
 static uint64_t gen_updates(const redux_params *p, uint32_t block_size) // increments a tree node of a block can receive
 {
     const uint64_t nsym    = (uint64_t)block_size * 8 / p->symbol_bits;
@@ -160,17 +158,22 @@ static uint64_t gen_updates(const redux_params *p, uint32_t block_size) // incre
 // the cell decoder takes the block: see above
 static bool gen_decode_cells(const redux_params *p, uint32_t block_size)
 {
-    const uint64_t count0 = (1ull << p->symbol_bits) + 1;
     if (p->symbol_bits >= 8)
         return gen_updates(p, block_size) + (1ull << (p->symbol_bits - 1)) <= 65535;
-    const uint64_t nfreeze = ((1ull << p->freq_bits) - 1) - count0;
-    return count0 + nfreeze < (1ull << 17) || (uint64_t)block_size * 8 / p->symbol_bits + count0 <= (1ull << 17) + 64;
+    return true;
+}
+// ... with the fix-up instance: the count passes 2^17 inside a block.  (By a few symbols only -- a 64 KiB block of 4-bit symbols
+// ends at 2^17 + 17 -- is not worth the instance's ~10 %: the plain one stops its lock-step loop there and its per-lane loop,
+// which divides exactly, codes the rest.)
+static bool gen_needs_fixup(const redux_params *p, uint32_t block_size)
+{
+    return p->symbol_bits < 8 && (1ull << p->symbol_bits) + 1 + gen_updates(p, block_size) > (1ull << 17) + 64;
 }
 static bool is_gen(const redux_params *p, uint32_t block_size)
 {
     if (p->code_bits > 32 || p->symbol_bits == 8 || p->symbol_bits > 12 || block_size > (1u << 22))
         return false;
-    return p->symbol_bits == 4 || gen_decode_cells(p, block_size);
+    return gen_decode_cells(p, block_size);
 }
 // 11- and 12-bit symbols: the bottom cells (2^(symbol_bits - 4) of 32 bytes per block: 4 / 8 KiB) live in the workspace, the
 // cells above them in LDS: 64 blocks per wave, four waves per CU (redux_decode_cells.hpp).  Measured against keeping everything
@@ -319,7 +322,7 @@ static uint32_t cu_count()
 // ---- which kernel a call runs: ONE decision, used by the launch code and reported by
 // redux_encode_kernel_name / redux_decode_kernel_name (bench.py's roofline.kernel) ------------
 enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Gen, GenPair, Any, CoopCb32, Coop };
-enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Cells, CellsWorkspace, Gen4, Any, Wave, WaveFixup };
+enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Cells, CellsFixup, CellsWorkspace, Any, Wave, WaveFixup };
 
 // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset; otherwise
 // (giant blocks, whole-stream mode) one block per wave.
@@ -359,8 +362,8 @@ static EncKernel pick_encode_kernel(const Geometry &g, const redux_params *p, bo
 static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p, uint64_t nslots = 0, uint32_t block_size = 0)
 {
     if (g.gen) {
-        if (!gen_decode_cells(p, block_size))
-            return DecKernel::Gen4;
+        if (gen_needs_fixup(p, block_size))
+            return DecKernel::CellsFixup;
         return gen_decode_in_workspace(p, nslots ? nslots : ~0ull) ? DecKernel::CellsWorkspace : DecKernel::Cells;
     }
     if (g.any)
@@ -448,7 +451,7 @@ const char *redux_decode_kernel_name_n(const redux_params *p, const void *d_out,
     case DecKernel::GenericU16: return "k_decode<true, false> (u16 tree, per-lane control flow)";
     case DecKernel::GenericU16Fixup: return "k_decode<true, true> (u16 tree, quotient fix-up)";
     case DecKernel::GenericU32: return "k_decode<false, true> (u32 tree)";
-    case DecKernel::Gen4: return "k_decode_gen<4> (4-bit symbols beyond 2^17 per block: per-level walk, u32 tree in LDS)";
+    case DecKernel::CellsFixup: // (the same kernels' instance for counts of 2^17 and more)
     case DecKernel::Cells:
     case DecKernel::CellsWorkspace: {
         // lock-step, the tree as cells of four levels: all of them in LDS (symbol_bits <= 10), or the bottom ones in the workspace
@@ -912,7 +915,14 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)d_workspace, g.rc_n, (1u << p->symbol_bits) + 1u);
         const uint32_t grid64 = (uint32_t)((nblocks + 63) / 64);
         switch (pick_decode_kernel(g, p, nblocks, block_size)) {
-        case DecKernel::Gen4: k_decode_gen<4><<<grid64, 64, 0, s>>>(ga); break;
+        case DecKernel::CellsFixup:
+            switch (p->symbol_bits) {
+#define REDUX_GEN_DEC(SB) case SB: k_decode_cells<SB, 64, false, true><<<grid64, 64, 0, s>>>(ga); break;
+                REDUX_GEN_DEC(1) REDUX_GEN_DEC(2) REDUX_GEN_DEC(3) REDUX_GEN_DEC(4) REDUX_GEN_DEC(5) REDUX_GEN_DEC(6) REDUX_GEN_DEC(7)
+#undef REDUX_GEN_DEC
+            default: return REDUX_UNSUPPORTED;
+            }
+            break;
         case DecKernel::CellsWorkspace: {
             // every tree starts at all-ones frequencies: a node = its lowbit
             const uint64_t npieces = (uint64_t)grid64 * 64 * gen_decode_tree_bytes(p) / 16;
@@ -1008,8 +1018,8 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     case DecKernel::GenericU16: k_decode<true, false><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::GenericU16Fixup: k_decode<true, true><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::GenericU32: k_decode<false, true><<<grid, 64, 0, s>>>(a); break;
-    case DecKernel::Gen4:
     case DecKernel::Cells:
+    case DecKernel::CellsFixup:
     case DecKernel::CellsWorkspace:
     case DecKernel::Any: break; // handled above
     }

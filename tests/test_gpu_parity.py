@@ -964,7 +964,8 @@ def test_kernel_names_follow_the_dispatch(rx):
     assert dec((5, 27, 32), 65536).startswith("k_decode_cells<5>")
     assert dec((11, 21, 32), 65536).startswith("k_decode_cells<11>")
     assert dec((4, 28, 32), 65536).startswith("k_decode_cells<4>")
-    assert dec((4, 28, 32), 1 << 20).startswith("k_decode_gen<4>")                       # count passes 2^17 early: the per-level walk
+    assert dec((4, 28, 32), 1 << 20).startswith("k_decode_cells<4>")                     # count passes 2^17: the same kernel's fix-up instance
+    assert dec((2, 30, 32), 65536).startswith("k_decode_cells<2>") and enc((2, 30, 32), 0, 1 << 20, 65536).startswith("k_encode_gen<2>")
     assert dec((13, 21, 32), 65536).startswith("k_decode_any")
     assert dec((8, 30, 32), 65536).startswith("k_decode_lock<true>")
     assert dec((8, 22, 24), 65536).startswith("k_decode_lock<false>")
@@ -1049,13 +1050,15 @@ def test_host_abi_from_two_threads_and_release(rx):
 
 @pytest.mark.parametrize("params", [(4, 10, 16), (4, 22, 24), (4, 28, 32), (12, 14, 16), (12, 18, 30), (12, 20, 32),
                                     (1, 3, 5), (2, 10, 16), (3, 12, 14), (5, 27, 32), (6, 9, 12), (7, 24, 30), (9, 11, 13), (10, 22, 32),
-                                    (11, 21, 32)])
+                                    (11, 21, 32), (1, 25, 30), (2, 30, 32), (3, 29, 32)])
 def test_lockstep_kernels_for_4_and_12_bit_symbols(rx, params):
     """The widths src/model/tests.rs:95-251 exercises besides 8 (4 and 12) and the ones between, on the lock-step kernels of
     redux_gen.hpp (encode) and redux_decode_cells.hpp (decode):
     64 KiB blocks (131,072 resp. 43,690 symbols: the model freezes inside the block for the narrow frequency
     widths, count passes 2^17 for 4-bit symbols), ragged tail, 70 blocks = two waves, streams bit-exact with the
-    oracle, decode equal to the oracle's decode (12-bit symbols: the trailing 8 bits of a 64 KiB block are dropped)."""
+    oracle, decode equal to the oracle's decode (12-bit symbols: the trailing 8 bits of a 64 KiB block are dropped).  The last
+    three triples have 174,762 to 524,288 symbols per block and models that do not freeze: the count passes 2^17 and the
+    kernels' fix-up instances run."""
     import ctypes as C
     from redux_amd import _lib
     p = _lib.Params(*params)
@@ -1249,6 +1252,22 @@ def test_host_calls_on_two_contexts_of_one_device(rx):
         api.host_set_chunk_bytes(0, 0)
     out4, offs4, _ = rx.compress_blocks(data[: 10 * bs], bs, (8, 30, 32))
     assert (offs4 == ref_offs[:11]).all()
+
+
+def test_4_bit_symbols_in_blocks_past_2_17_symbols(rx):
+    """256 KiB blocks of 4-bit symbols: 524,288 symbols, the count passes 2^17 a quarter of the way in (round 3: the per-level
+    k_decode_gen<4>; now k_decode_cells<4>'s fix-up instance and k_encode_gen<4>'s fix-up turns).  A whole wave + a ragged one."""
+    rng = np.random.default_rng(44)
+    bs = 262144
+    data = (rng.integers(0, 256, 66 * bs - 777, dtype=np.uint8) >> rng.integers(0, 5)).astype(np.uint8)
+    P = (4, 28, 32)
+    out, offs, st = rx.compress_blocks(data, bs, P)
+    assert not st.any() and len(offs) == 67
+    for b in (0, 31, 63, 64, 65):
+        assert out[int(offs[b]): int(offs[b + 1])].tobytes() == ox.compress(data[b * bs:(b + 1) * bs].tobytes(), P)[0], b
+    dec, sizes, dst = rx.decompress_blocks(out, offs, bs, P)
+    assert not dst.any() and int(sizes.sum()) == len(data)
+    assert (dec[: 65 * bs] == data[: 65 * bs]).all() and (dec[65 * bs:][: bs - 777] == data[65 * bs:]).all()
 
 
 def test_gen_kernels_hand_large_blocks_to_the_one_lane_kernels(rx):
