@@ -235,7 +235,10 @@ int redux_decode_blocks_v_dev(const redux_params *p, const void *d_in, const voi
 
 /* The two phases of redux_encode_blocks_dev, exposed so a harness can time the coder kernel
  * by itself: (1) code every block into its padded slot inside the workspace and record the
- * sizes; (2) scan the sizes and gather the slots into the dense output. */
+ * sizes; (2) scan the sizes and gather the slots into the dense output.  Both take the same
+ * (in_len, block_size, d_workspace, workspace_bytes): the layout inside the workspace is a function of
+ * the shape AND of workspace_bytes (a workspace without room for the small-launch kernels' pairs area
+ * makes a small launch run the full-grid kernels on their layout), so the phases must be told the same. */
 int redux_encode_slots_dev(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size,
                            void *d_block_status, void *d_workspace, uint64_t workspace_bytes, void *stream);
 int redux_compact_slots_dev(const redux_params *p, uint64_t in_len, uint32_t block_size, void *d_out, uint64_t out_cap,
