@@ -37,6 +37,9 @@ constexpr uint64_t kCoopMaxBlocks = 2048; // slots, idle table entries included 
 constexpr uint64_t kCoopMaxPairBytes = 3ull << 29; // ... and never more than 1.5 GiB
 constexpr uint32_t kCoopMinBlock  = 1024; // shorter blocks: the per-block set-up (scan, tree build) outweighs the model
 constexpr uint32_t kCoopSlack     = 64;   // symbols of slack behind a group's pairs (the chain wave prefetches unclamped)
+// Blocks above 64 KiB are coded in windows (EncArgs::win0): the pairs of one window of all blocks take at most this much ...
+constexpr uint64_t kCoopWindowBytes = 512ull << 20;
+constexpr uint64_t kCoopWindowMax   = 1ull << 20; // ... and a window is at most this many symbols (8 MiB of pairs and of reciprocals per block)
 
 // inclusive sum over the wave's lanes 0 .. lane
 __device__ __forceinline__ uint32_t coop_wave_scan(uint32_t v, uint32_t lane)
@@ -71,8 +74,11 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
         src = a.in + ent * a.block_size;
         len = rem < a.block_size ? (uint32_t)rem : a.block_size;
     }
-    if (len == 0)
+    // this launch's window of the block: symbols [w0, w0 + lenw)
+    const uint32_t w0 = a.win0;
+    if (len <= w0)
         return;
+    const uint32_t lenw = len - w0 < a.winlen ? len - w0 : a.winlen;
     for (uint32_t i = lane; i < TreeT::kDwords / 4; i += 64)
         reinterpret_cast<uint4 *>(lds)[i] = make_uint4(0, 0, 0, 0);
     TreeT T;
@@ -81,8 +87,9 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
 
     // this lane's symbols [b0, b1), read as the aligned 16-byte pieces of memory that contain them (the bytes of a piece
     // outside the block are in the same page as bytes inside it)
-    const uint32_t  seg = (len + 63) / 64;
-    const uint32_t  b0 = lane * seg < len ? lane * seg : len, b1 = b0 + seg < len ? b0 + seg : len;
+    const uint32_t  seg = (lenw + 63) / 64;
+    const uint32_t  r0 = lane * seg < lenw ? lane * seg : lenw, r1 = r0 + seg < lenw ? r0 + seg : lenw;
+    const uint32_t  b0 = w0 + r0, b1 = w0 + r1;
     const uintptr_t A0 = (uintptr_t)src + b0, A1 = (uintptr_t)src + b1, C0 = A0 & ~(uintptr_t)15;
     const uint32_t  npieces = b1 > b0 ? (uint32_t)((A1 - C0 + 15) >> 4) : 0u;
     const uint32_t  maxpieces = __builtin_amdgcn_readfirstlane(wave_max(npieces));
@@ -106,16 +113,36 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
         }
     }
     __syncthreads();
-    // ---- 2. row r: counts of symbol r - 1 in the segments BEFORE this lane's (exclusive scan over the lanes)
-    for (uint32_t r = 1; r < 256; r++) {
-        const uint32_t v    = T.node((r << TreeT::kShift) | T.L);
-        const uint32_t incl = coop_wave_scan(v, lane);
-        char          *cell = reinterpret_cast<char *>(lds) + ((r << TreeT::kShift) | T.L);
-        if (U16)
-            *reinterpret_cast<uint16_t *>(cell + 2 * (lane >> 5)) = (uint16_t)(incl - v);
-        else
-            *reinterpret_cast<uint32_t *>(cell) = incl - v;
+    // ---- 2. row r: counts of symbol r - 1 in the segments BEFORE this lane's (exclusive scan over the lanes) -- and, when
+    //         the block is coded in windows, in the windows before this one: cbase row r of the block, lane l holding
+    //         rows 4l .. 4l + 3 of it while the scan runs, updated with this window's totals for the next one
+    uint4 *basep = (!U16 && a.cbase) ? reinterpret_cast<uint4 *>(a.cbase + ent * 256) + lane : nullptr; // (wave-uniform null-ness)
+    uint4  bq    = (basep && w0) ? *basep : make_uint4(0, 0, 0, 0);
+    for (uint32_t r4 = 0; r4 < 64; r4++) {
+        const uint32_t bw[4] = {bq.x, bq.y, bq.z, bq.w};
+        uint32_t       nw[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t r = 4 * r4 + k;
+            if (r == 0)
+                continue;
+            const uint32_t v    = T.node((r << TreeT::kShift) | T.L);
+            const uint32_t incl = coop_wave_scan(v, lane);
+            const uint32_t br   = basep ? (uint32_t)__shfl((int)bw[k], (int)r4) : 0u;
+            char          *cell = reinterpret_cast<char *>(lds) + ((r << TreeT::kShift) | T.L);
+            if (U16)
+                *reinterpret_cast<uint16_t *>(cell + 2 * (lane >> 5)) = (uint16_t)(incl - v);
+            else
+                *reinterpret_cast<uint32_t *>(cell) = incl - v + br;
+            if (basep) {
+                const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
+                nw[k] = lane == r4 ? br + tot : nw[k];
+            }
+        }
+        bq = make_uint4(nw[0], nw[1], nw[2], nw[3]);
     }
+    if (basep)
+        *basep = bq;
     __syncthreads();
     // ---- 3. the Fenwick form in place (node i also covers node i - lowbit(i) + ... : adaptive_tree.rs:43-59): d[i] is
     //         the number of increments node i has received after the symbols before this segment
@@ -127,7 +154,7 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
         }
     }
     // ---- 4. query + update over the segment (adaptive_tree.rs:63-92), pairs out
-    uint2 *pg = pairs + ((ent >> 6) * ((uint64_t)a.block_size + kCoopSlack)) * a.pair_width + (ent & 63);
+    uint2 *pg = pairs + ((ent >> 6) * ((uint64_t)a.winlen + kCoopSlack)) * a.pair_width + (ent & 63);
     {
         uint4 nx = npieces ? piece(0) : make_uint4(0, 0, 0, 0);
         for (uint32_t k = 0; k < maxpieces; k++) {
@@ -145,7 +172,7 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
                     uint32_t       lo, hi;
                     // (the update of a block's last symbol is unobservable and skipped: u16 nodes, Tree)
                     T.template get_frequency<true>(s, nup, q < a.nfreeze && (!U16 || q + 1 != len), lo, hi);
-                    pg[(uint64_t)q * a.pair_width] = make_uint2(lo, hi);
+                    pg[(uint64_t)(q - w0) * a.pair_width] = make_uint2(lo, hi);
                 }
             }
         }
@@ -270,11 +297,15 @@ __device__ __forceinline__ void emit_careful(EncState &S, uint32_t topk, uint32_
 }
 
 // LINEAR: the launch has fewer than 64 (large) blocks and its slots are linear -- a lane's dwords contiguous in its own
-// slot, lanes without a block in the spare slot behind the last one -- instead of one row-major area of 64 slots: the
-// workspace of such a launch (ONE block of any length above all: redux_compress) then holds nblocks + 1 slots, not 65.
-template <bool CB32, bool FIXUP, bool LINEAR = false>
+// slot -- instead of one row-major area of 64 slots: the workspace of such a launch (ONE block of any length above all:
+// redux_compress) then holds nblocks slots, not 64.
+// WIN: the launch codes one window of blocks that are coded window by window (every launch of blocks above 64 KiB); a lane
+// without a symbol in the window then sends EMPTY messages instead of coding a copy of a neighbour's symbols -- its slot may
+// hold a block that ended in an earlier window -- and stores nothing at all, so linear slots need no spare one.
+template <bool CB32, bool FIXUP, bool LINEAR = false, bool WIN = LINEAR>
 __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pairs)
 {
+    static_assert(WIN || !LINEAR, "linear slots: blocks above 64 KiB, coded in windows");
     constexpr int ST = LINEAR ? (4 | kSwapped) : kPairStride;
     __shared__ uint2 ring[kCoopRing / 8];
     __shared__ uint2 fin[64]; // (low after the EOF symbol, its shifts): what encode_finish needs from the chain
@@ -282,22 +313,34 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t blk0 = (uint64_t)blockIdx.x * 64;
     const uint64_t blk  = blk0 + lane;
-    const bool     live = blk < a.nblocks && !(a.table && a.table[blk].index == kIdleEntry);
+    const bool     has  = blk < a.nblocks && !(a.table && a.table[blk].index == kIdleEntry);
     const uint8_t *wsrc;
-    const EncLane  EL  = enc_lane(a, blk0, blk, lane, live, wsrc);
-    const uint32_t len = EL.len;
-    const uint32_t minlen = __builtin_amdgcn_readfirstlane(wave_min(live ? len : 0xFFFFFFFFu));
-    const uint32_t maxlen = __builtin_amdgcn_readfirstlane(wave_max(live ? len : 0u));
+    const EncLane  EL  = enc_lane(a, blk0, blk, lane, has, wsrc);
+    // This launch codes the window [w0, w0 + wl) of every block (a.win0, a.winlen: redux_encode.hpp; one window of
+    // block_size + 1 symbols when the pairs of whole blocks fit the workspace).  Positions below are window-relative: a lane
+    // is live while its block has not ended before the window (its EOF symbol is coded in the window that holds symbol
+    // number `len`), it has `nd` data symbols here, acts on positions 0 .. lastq, and eofq is its EOF symbol's position.
+    const uint32_t w0   = WIN ? a.win0 : 0u, wl = a.winlen;
+    const bool     live = has && EL.len >= w0;
+    const uint32_t lend = EL.len - w0;
+    const uint32_t nd   = lend < wl ? lend : wl;
+    const uint32_t eofq = lend < wl ? lend : 0xFFFFFFFFu;
+    const uint32_t lastq = lend < wl ? lend : wl - 1u;
+    const uint32_t minlen = __builtin_amdgcn_readfirstlane(wave_min(live ? nd : 0xFFFFFFFFu));
+    const uint32_t maxlast = __builtin_amdgcn_readfirstlane(wave_max(live ? lastq : 0u));
     const uint32_t sh     = 32 - a.code_bits;
     const rc_ptr   rc     = (rc_ptr)a.rc;
     const uint32_t nfreeze = a.nfreeze;
+    const uint32_t nfz_w  = nfreeze > w0 ? nfreeze - w0 : 0u; // the freeze point, window-relative
     const uint64_t lives  = __builtin_amdgcn_ballot_w64(live);
     if (lives == 0)
         return;
     uint32_t main_end = 0;
     if (minlen > 16)
         main_end = (minlen - 1) & ~15u;
-    const uint32_t nperiods = (maxlen + 1 + kPeriod - 1) / kPeriod; // symbols 0 .. maxlen (the longest block's EOF)
+    const uint32_t nperiods = (maxlast + 1 + kPeriod - 1) / kPeriod; // positions 0 .. maxlast (the longest block's last one)
+    uint32_t      *stp = (WIN && a.cstate && live) ? a.cstate + blk * 8 : nullptr; // this block's state between windows
+    const uint32_t lmask = (!WIN || live) ? 0xFFFFFFFFu : 0u;
     auto slot = [&](uint32_t i) { return ring + ((i >> 1) * 128u + lane * 2u); }; // symbols i (even) and i + 1 of this lane, i < 2 kPeriod
 
     if (wave == 0) {
@@ -306,7 +349,7 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
         // column of the workspace was never written) and sends empty messages after it
         const uint32_t col  = live ? lane : (uint32_t)__builtin_ctzll(lives);
         const uint32_t pw   = a.pair_width; // lanes per row of the pairs: 64, or the number of blocks of a launch of fewer
-        const uint64_t gcol = (uint64_t)blockIdx.x * ((uint64_t)a.block_size + kCoopSlack) * pw;
+        const uint64_t gcol = (uint64_t)blockIdx.x * ((uint64_t)a.winlen + kCoopSlack) * pw;
         const uint2   *pg   = pairs + gcol + col;
         auto load16 = [&](uint2 (&d)[16], uint32_t p) { // (up to 47 symbols past the last chunk: inside the slack)
             const uint2 *q = pg + (uint64_t)p * pw;
@@ -326,7 +369,10 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
         };
         ChainState X;
         X.low = 0; X.ih = 0; X.r1 = 0xFFFFFFFFu;
-        const double rcF = rc[maxlen < nfreeze ? maxlen : nfreeze]; // (the table ends at min(longest block, freeze point) + slack)
+        if (stp && w0) {
+            X.low = stp[0]; X.ih = stp[1]; X.r1 = stp[2];
+        }
+        const double rcF = a.rc_frozen;
         // Chunks of 16 symbols; the pairs of chunk c + 2 are requested when chunk c starts (three register buffers whose
         // roles rotate: the loop is unrolled by three so that no copy -- which would wait for the newest loads -- moves
         // them).  Every chunk is loaded without a lane predicate (a short block's column is garbage behind its end, the
@@ -351,21 +397,23 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
             // in flight (vmcnt(32); the lgkmcnt / expcnt fields all ones = no wait)
             __builtin_amdgcn_s_waitcnt(0x8F70);
             if (HOT || p + 16 <= main_end) {
-                const uint32_t pb = HOT ? p : (p < nfreeze ? p : nfreeze); // (sixteen consecutive entries: inside the table's slack)
-                double         r[16];
+                double r[16]; // (the table covers the window + slack: rc[i] belongs to count 257 + w0 + i)
 #pragma unroll
                 for (int i = 0; i < 16; i++)
-                    r[i] = rc[pb + i];
+                    r[i] = rc[p + i];
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
                     uint2 m[2];
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
-                        const bool     upd = HOT || p + i + e < nfreeze;
-                        const uint32_t n   = upd ? p + i + e : nfreeze;
+                        const bool     upd = HOT || p + i + e < nfz_w;
+                        const uint32_t n   = upd ? w0 + p + i + e : nfreeze;
                         m[e] = chain_step<CB32, FIXUP>(X, cur[i + e].x, cur[i + e].y, 257u + n, upd ? r[i + e] : rcF, sh);
                     }
-                    *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m[0].x, m[0].y, m[1].x, m[1].y);
+                    if (WIN)
+                        *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m[0].x & lmask, m[0].y & lmask, m[1].x & lmask, m[1].y & lmask);
+                    else
+                        *reinterpret_cast<uint4 *>(slot(ro + i)) = make_uint4(m[0].x, m[0].y, m[1].x, m[1].y);
                 }
             } else {
 #pragma unroll
@@ -374,11 +422,12 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         const uint32_t q   = p + i + e;
-                        const bool     act = live && q <= len, eof = q == len;
-                        const uint32_t qm  = q < maxlen ? q : maxlen;      // (the reciprocal table ends at min(maxlen, nfreeze) + slack)
-                        const uint32_t qc  = qm < nfreeze ? qm : nfreeze; // updates before symbol q
+                        const bool     act = live && q <= lastq, eof = q == eofq;
+                        const bool     upd = q < nfz_w;
+                        const uint32_t qc  = upd ? w0 + q : nfreeze; // updates before symbol q
+                        const uint32_t qr  = q < wl + 32u ? q : wl + 32u; // (the table ends 64 entries behind the window)
                         uint32_t       shifts;
-                        m[e] = chain_step_any<CB32, FIXUP>(X, eof ? 256u + qc : cur[i + e].x, cur[i + e].y, 257u + qc, rc[qc], sh, act, eof, shifts);
+                        m[e] = chain_step_any<CB32, FIXUP>(X, eof ? 256u + qc : cur[i + e].x, cur[i + e].y, 257u + qc, upd ? rc[qr] : rcF, sh, act, eof, shifts);
                         if (act && eof)
                             fin[lane] = make_uint2(X.low, shifts);
                     }
@@ -391,7 +440,7 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
         typedef std::integral_constant<int, 0> U0;
         typedef std::integral_constant<int, 1> U1;
         typedef std::integral_constant<int, 2> U2;
-        const uint32_t hot_end = main_end < nfreeze ? main_end : nfreeze; // symbols that are lock-step AND adaptive
+        const uint32_t hot_end = main_end < nfz_w ? main_end : nfz_w; // symbols that are lock-step AND adaptive
         uint32_t       c0      = 0;
         for (; 16 * (c0 + 3) <= hot_end; c0 += 3) { // whole triples of hot chunks: one straight run of code
             chunk(U0(), std::true_type(), c0);
@@ -405,16 +454,23 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
             if (c0 + 2 < nchunks)
                 chunk(U2(), std::false_type(), c0 + 2);
         }
+        if (stp && eofq == 0xFFFFFFFFu) { // the block goes on in the next window
+            stp[0] = X.low; stp[1] = X.ih; stp[2] = X.r1;
+        }
         return;
     }
 
     // ---------------- emit wave ----------------
     uint8_t       *wdst  = LINEAR ? a.slots : a.slots + (uint64_t)blockIdx.x * (64 * a.slot_bytes + 128);
-    const uint32_t off0  = LINEAR ? (live ? lane : (uint32_t)a.nblocks) * (uint32_t)a.slot_bytes : lane * 4u;
+    const uint32_t off0  = LINEAR ? (live ? lane : 0u) * (uint32_t)a.slot_bytes : lane * 4u; // (LINEAR: a lane that is not live never stores)
     const uint32_t limit = LINEAR ? off0 + (a.slot_cap & ~3u) : off0 + (a.slot_cap / 4u) * 256u;
     constexpr uint32_t kChunkBudget = (16 * 4 + 32) * (stride_of<ST> / 4);
     EncState S;
     enc_init(S, off0);
+    if (stp && w0) {
+        S.pend = stp[3]; S.nb = stp[4]; S.off = stp[5];
+        S.acc  = ((uint64_t)stp[7] << 32) | stp[6];
+    }
     for (uint32_t t = 0; t < nperiods; t++) {
         pair_barrier();
 #pragma unroll
@@ -450,7 +506,7 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                             emit_careful<ST>(S, msg[8 * g + i].x, msg[8 * g + i].y, wdst, 0xFFFFFFFFu);
                     }
                     const uint32_t pg = p + 8 * g;
-                    if (pg + 8 > main_end && live && len >= pg && len < pg + 8) { // this lane's EOF symbol was among the eight
+                    if (pg + 8 > main_end && live && eofq >= pg && eofq - pg < 8u) { // this lane's EOF symbol was among the eight
                         const uint2 f = fin[lane];
                         S.low         = f.x;
                         const uint32_t size = encode_finish<ST>(S, f.y, a.code_bits, off0, wdst, limit);
@@ -466,9 +522,9 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                     for (int k = 1; k < 16; k++)
                         mg = i == (uint32_t)k ? msg[k] : mg;
                     const uint32_t q = p + i;
-                    if (q < main_end || (live && q <= len)) // (below main_end dead lanes code their copy, in step with the chain wave)
+                    if (q < main_end || (live && q <= lastq)) // (below main_end the other lanes get empty messages)
                         emit_careful<ST>(S, mg.x, mg.y, wdst, limit);
-                    if (live && q == len) {
+                    if (live && q == eofq) {
                         const uint2 f = fin[lane];
                         S.low         = f.x;
                         const uint32_t size = encode_finish<ST>(S, f.y, a.code_bits, off0, wdst, limit);
@@ -478,6 +534,10 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
                 }
             }
         }
+    }
+    if (stp && eofq == 0xFFFFFFFFu) { // the block goes on in the next window
+        stp[3] = S.pend; stp[4] = S.nb; stp[5] = S.off;
+        stp[6] = (uint32_t)S.acc; stp[7] = (uint32_t)(S.acc >> 32);
     }
 }
 

@@ -53,6 +53,13 @@ struct EncArgs {
     // status belong to entry `index` of the output tables.
     const redux_block *table;
     uint32_t       pair_width; // small-grid kernels (redux_coop.hpp): lanes per row of the (low, high) pairs in the workspace
+    // ... which code a launch's blocks in WINDOWS of winlen symbols, one pair of kernel launches per window (the pairs area
+    // holds one window): symbols [win0, win0 + winlen) of every block, the EOF symbol of a block that ends inside them
+    // included.  rc[i] is then the reciprocal of count 257 + win0 + i, rc_frozen the frozen model's; cstate / cbase carry
+    // a block's coder state (8 words) and symbol counts (256 words) from window to window (null: a single window).
+    uint32_t       win0, winlen;
+    double         rc_frozen;
+    uint32_t      *cstate, *cbase;
 };
 
 // A table entry with this index is an idle lane: redux_block_table_v pads the table with them so that blocks of very
@@ -154,7 +161,10 @@ __global__ void __launch_bounds__(64) k_encode(EncArgs a)
     uint8_t       *wdst  = a.slots + blk0 * a.slot_bytes;
     // Dead lanes of the last wave run the same instruction stream on block blk0's bytes and
     // store into the spare slot behind the last real one, so the hot loop needs no predicate.
-    const uint32_t off0  = live ? lane * (uint32_t)a.slot_bytes : (uint32_t)(a.nblocks - blk0) * (uint32_t)a.slot_bytes;
+    // One block per wave (giant blocks: a.lanes == 1): the 63 other lanes mirror lane 0 -- the same bytes, the same state --
+    // and store what it stores where it stores it (a spare slot would lie beyond a 32-bit offset as soon as 64 slots do).
+    const uint32_t off0  = live ? lane * (uint32_t)a.slot_bytes
+                                : (a.lanes == 1 ? 0u : (uint32_t)(a.nblocks - blk0) * (uint32_t)a.slot_bytes);
     const uint32_t limit = off0 + a.slot_cap;
 
     // The lock-step loop covers [0, maxlen]; the unrolled path covers whole 16-byte chunks

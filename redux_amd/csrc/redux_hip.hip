@@ -123,8 +123,10 @@ struct Geometry {
     bool     coop;       // small grid: k_coop_model + k_coop_chain (redux_coop.hpp), (low, high) pairs in the workspace
     bool     coop_linear; // ... with fewer than 64 large blocks: linear slots, nblocks + 1 of them (k_coop_chain<.., LINEAR>)
     uint32_t pair_width; // ... in rows of this many lanes
+    uint32_t coop_win;   // ... one WINDOW of this many symbols of every block at a time (block_size + 1: whole blocks), coop_nwin of them
+    uint32_t coop_nwin;
     // workspace layout (encode)
-    uint64_t off_rc, off_sizes, off_mode, off_slots, off_trees, off_table, off_seen, off_pairs, total;
+    uint64_t off_rc, off_sizes, off_mode, off_slots, off_trees, off_table, off_seen, off_cstate, off_pairs, total;
 };
 
 static int check_params(const redux_params *p)
@@ -260,23 +262,46 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     // redux_compress, the literal redux::compress -- is such a grid.  The pairs are rows of pair_width lanes (64, or the
     // number of blocks when there are fewer and they are large), block_size + slack rows per group of 64 blocks.
     g.pair_width = (g.nblocks < 64 && !g.u16) ? (uint32_t)g.nblocks : 64u; // (large blocks only: a constant row stride is faster to address)
-    const uint64_t pair_bytes = (g.nblocks + 63) / 64 * g.pair_width * ((uint64_t)block_size + kCoopSlack) * 8;
+    // Blocks of up to 64 KiB: the pairs of whole blocks (8 bytes per input byte).  Larger blocks -- one stream of any length
+    // above all -- are coded in windows, one (model, chain) pair of launches per window, so that the pairs area and the
+    // reciprocal table hold one window whatever the block length: the largest window whose pairs fit kCoopWindowBytes, at most
+    // kCoopWindowMax symbols, the windows together covering block_size + 1 symbols (the last one holds a full block's EOF).
+    const uint64_t lanes_total = (g.nblocks + 63) / 64 * g.pair_width;
+    g.coop_win  = block_size + 1;
+    g.coop_nwin = 1;
+    if (!g.u16) {
+        uint64_t w = kCoopWindowBytes / (8 * lanes_total);
+        w = w > kCoopWindowMax ? kCoopWindowMax : w;
+        w = w < 4096 ? 4096 : w;
+        if (w < (uint64_t)block_size + 1) {
+            g.coop_nwin = (uint32_t)(((uint64_t)block_size + 1 + w - 1) / w);
+            g.coop_win  = (uint32_t)((((uint64_t)block_size + 1 + g.coop_nwin - 1) / g.coop_nwin + 31) & ~31ull);
+        }
+    }
+    const uint64_t pair_bytes = lanes_total * ((uint64_t)g.coop_win + kCoopSlack) * 8;
+    // fewer than 64 large blocks on the small-grid kernels: linear slots, one per block (a row-major group area is 64 slots
+    // big whatever the number of blocks: 230 MiB to code one 3 MiB stream); a lane addresses its slot with 32-bit offsets
+    const bool linear = g.nblocks < 64 && !g.u16;
     g.coop = allow_coop && !static_model && !g.any && !g.gen && g.nblocks <= kCoopMaxBlocks && block_size >= kCoopMinBlock &&
-             64ull * g.slot_bytes < (1ull << 32) && pair_bytes <= kCoopMaxPairBytes;
-    // fewer than 64 large blocks on the small-grid kernels: linear slots, one per block + a spare one for the lanes without
-    // a block (a row-major group area is 64 slots big whatever the number of blocks: 230 MiB to code one 3 MiB stream)
-    g.coop_linear = g.coop && g.nblocks < 64 && !g.u16;
+             (linear ? g.nblocks : 64ull) * g.slot_bytes < (1ull << 32) && pair_bytes <= kCoopMaxPairBytes;
+    if (g.coop) // the reciprocals of one window (+ what the chain wave reads ahead)
+        g.rc_n = g.coop_win + 64;
+    g.coop_linear = g.coop && linear;
     g.off_rc    = 0;
     g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
     g.off_mode  = align_up(g.off_sizes + g.nblocks * 4, 256); // one word: 0 linear slots, != 0 row-major group areas
     g.off_slots = g.off_mode + 256 + kClaimWords * 4; // mode word, then k_encode_pair's role book
-    // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode
-    const uint64_t nslots = g.coop_linear ? g.nblocks + 1 : (g.nblocks + 63) / 64 * 64 + 1;
+    // whole groups of 64 slots (a row-major group area is 64 slots big) + 1 spare slot for the dead lanes of linear mode;
+    // giant blocks (one per wave, encode_lanes()) and the small-grid kernels' linear slots: one per block
+    const bool     one_each = g.coop_linear || (!g.any && !g.gen && !static_model && !g.coop && 64ull * g.slot_bytes >= (1ull << 32));
+    const uint64_t nslots = one_each ? g.nblocks : (g.nblocks + 63) / 64 * 64 + 1;
     g.off_trees = align_up(g.off_slots + nslots * g.slot_bytes + (g.nblocks + 63) / 64 * 128, 256);
     // the checked copy of a `_v_dev` call's block table + the bitmap of block numbers its check uses (redux_table.hpp)
     g.off_table = align_up(g.off_trees + (g.gen ? (g.nblocks + 63) / 64 * 64 : g.nblocks) * g.tree_bytes, 256); // gen: whole waves
     g.off_seen  = g.off_table + align_up(g.nblocks * sizeof(redux_block), 256);
-    g.off_pairs = g.off_seen + align_up(table_seen_words(g.nblocks) * 4, 256);
+    // small-grid kernels, blocks coded in windows: 8 words of coder state + 256 symbol counts per block, carried between windows
+    g.off_cstate = g.off_seen + align_up(table_seen_words(g.nblocks) * 4, 256);
+    g.off_pairs  = g.off_cstate + ((g.coop && g.coop_nwin > 1) ? align_up(g.nblocks * (8 + 256) * 4, 256) : 0);
     g.total = g.off_pairs + (g.coop ? pair_bytes : 0);
     return g;
 }
@@ -611,6 +636,7 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
     a.claims     = (uint32_t *)(ws + g.off_mode + 256);
     a.table      = d_table;
     a.pair_width = g.pair_width;
+    a.win0 = 0; a.winlen = block_size + 1; a.rc_frozen = 0.0; a.cstate = nullptr; a.cbase = nullptr;
     // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset;
     // otherwise (giant blocks, whole-stream mode) one block per wave.
     a.lanes = encode_lanes(g, block_size);
@@ -626,24 +652,49 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
         uint2         *pairs = (uint2 *)(ws + g.off_pairs);
         const uint32_t cgrid = (uint32_t)((g.nblocks + 63) / 64);
         const bool     cb32  = which == EncKernel::CoopCb32;
-        if (g.u16)
-            k_coop_model<true><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
-        else
-            k_coop_model<false><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
-        if (g.coop_linear) {
-            if (g.fixup) {
-                if (cb32) k_coop_chain<true, true, true><<<cgrid, 128, 0, s>>>(a, pairs);
-                else      k_coop_chain<false, true, true><<<cgrid, 128, 0, s>>>(a, pairs);
+        {
+            const double r = 1.0 / (double)(257ull + g.nfreeze); // the frozen model's reciprocal, biased as k_fill_rc's
+            uint64_t     u;
+            memcpy(&u, &r, 8);
+            u += 4;
+            memcpy(&a.rc_frozen, &u, 8);
+        }
+        a.winlen = g.coop_win;
+        a.cstate = g.coop_nwin > 1 ? (uint32_t *)(ws + g.off_cstate) : nullptr;
+        a.cbase  = a.cstate ? a.cstate + g.nblocks * 8 : nullptr;
+        // the longest block of the launch: its EOF symbol (symbol number `length`) is the last one coded
+        const uint64_t longest = d_table ? block_size : (in_len < block_size ? in_len : block_size);
+        for (uint32_t w = 0; w < g.coop_nwin && (uint64_t)w * g.coop_win <= longest; w++) {
+            a.win0 = w * g.coop_win;
+            if (w) // (the first window's table was filled above)
+                k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)(ws + g.off_rc), g.rc_n, 257u + a.win0);
+            if (g.u16)
+                k_coop_model<true><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
+            else
+                k_coop_model<false><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
+            if (g.coop_linear) {
+                if (g.fixup) {
+                    if (cb32) k_coop_chain<true, true, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                    else      k_coop_chain<false, true, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                } else {
+                    if (cb32) k_coop_chain<true, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                    else      k_coop_chain<false, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                }
+            } else if (!g.u16) { // 64 and more blocks above 64 KiB: row-major group areas, coded in windows
+                if (g.fixup) {
+                    if (cb32) k_coop_chain<true, true, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                    else      k_coop_chain<false, true, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                } else {
+                    if (cb32) k_coop_chain<true, false, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                    else      k_coop_chain<false, false, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                }
+            } else if (g.fixup) {
+                if (cb32) k_coop_chain<true, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                else      k_coop_chain<false, true><<<cgrid, 128, 0, s>>>(a, pairs);
             } else {
-                if (cb32) k_coop_chain<true, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
-                else      k_coop_chain<false, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
+                if (cb32) k_coop_chain<true, false><<<cgrid, 128, 0, s>>>(a, pairs);
+                else      k_coop_chain<false, false><<<cgrid, 128, 0, s>>>(a, pairs);
             }
-        } else if (g.fixup) {
-            if (cb32) k_coop_chain<true, true><<<cgrid, 128, 0, s>>>(a, pairs);
-            else      k_coop_chain<false, true><<<cgrid, 128, 0, s>>>(a, pairs);
-        } else {
-            if (cb32) k_coop_chain<true, false><<<cgrid, 128, 0, s>>>(a, pairs);
-            else      k_coop_chain<false, false><<<cgrid, 128, 0, s>>>(a, pairs);
         }
         break;
     }

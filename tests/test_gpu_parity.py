@@ -1397,6 +1397,66 @@ def test_small_grid_kernels_on_large_blocks(rx):
         assert not dst.any() and b"".join(dec[b * bs: b * bs + int(sizes[b])].tobytes() for b in range(len(sizes))) == data
 
 
+def _coop_window(nentries, block_size):
+    """geometry() of redux_hip.hip: the window (symbols) the small-launch kernels code a launch of large blocks in."""
+    lanes = nentries if nentries < 64 else (nentries + 63) // 64 * 64
+    w = max(4096, min(1 << 20, (512 << 20) // (8 * lanes)))
+    if w >= block_size + 1:
+        return block_size + 1, 1
+    nwin = (block_size + 1 + w - 1) // w
+    return ((block_size + 1 + nwin - 1) // nwin + 31) & ~31, nwin
+
+
+@pytest.mark.parametrize("params,bs,nfull", [((8, 30, 32), 2_500_000, 1), ((8, 20, 24), 2_500_000, 1), ((8, 14, 16), 2_500_000, 0),
+                                             ((8, 30, 32), 600_000, 58)])
+def test_small_grid_kernels_code_long_blocks_in_windows(rx, params, bs, nfull):
+    """Blocks past 64 KiB on the small-launch kernels are coded window by window (EncArgs::win0: the pairs area and the
+    reciprocal table hold one window, the coder state and the symbol counts of a block travel in the workspace).  Block
+    lengths on and around the window edges -- a block that ends exactly at an edge has its EOF symbol alone in the next
+    window --, blocks that end windows before the others (their lanes must leave their finished slots alone: linear slots
+    with fewer than 64 entries, row-major group areas with more), a model that freezes inside a later window (20 frequency
+    bits) or in the first one (14).  Every stream equals the oracle's; the workspace stays far below the 8 bytes of pairs per
+    input byte that whole blocks would take."""
+    import ctypes as C
+    from redux_amd import _lib
+    rng = np.random.default_rng(bs + sum(params))
+    L = _lib.lib()
+    cp = _lib.Params(*params)
+
+    def lengths(win):
+        return [win, win - 1, win + 1, 2 * win, 2 * win + 5, bs, 0, 1, 777, win - 16, win + 17, bs - 1] + [bs] * nfull
+
+    # the table's entries decide the window, the window decides the lengths: settle on a fixed point
+    win, nwin = _coop_window(12 + nfull, bs)
+    for _ in range(4):
+        lens = [n for n in lengths(win) if n <= bs]
+        offs = np.cumsum([0] + lens[:-1])
+        ne = len(rx.block_table_v(offs, lens, bs))
+        win2, nwin = _coop_window(ne, bs)
+        if win2 == win:
+            break
+        win = win2
+    assert win2 == win and nwin >= 2, (win, win2, nwin)
+    assert b"k_coop_model" in L.redux_encode_kernel_name(C.byref(cp), None, ne * bs, bs)
+    # (the slots, and at most 512 MiB of pairs + change: whole blocks would take 8 bytes of pairs per input byte of every entry)
+    assert L.redux_encode_workspace_bytes(C.byref(cp), ne * bs, bs) < (ne + 65) * (L.redux_encode_slot_bytes(C.byref(cp), bs) + 256) + (600 << 20)
+    text = open(os.path.join(GOLDEN, "corpora", "large", "world192.txt"), "rb").read()
+    datas = []
+    for i, n in enumerate(lens):
+        if i % 3 == 0:
+            datas.append((text * (n // len(text) + 1))[:n])
+        else:
+            datas.append(bytes((rng.integers(0, 256, n, dtype=np.uint8) >> rng.integers(0, 6)).tolist()))
+    out, o, st, first = rx.compress_blocks_v(datas, bs, params)
+    assert not st.any() and len(o) - 1 == len(lens)
+    for b, d in enumerate(datas):
+        if b < 14 or b % 16 == 0:  # (the full blocks behind the first ones: every sixteenth against the oracle, all of them decoded)
+            want, _ = ox.compress(d, params)
+            assert out[int(o[b]): int(o[b + 1])].tobytes() == want, (params, b, len(d))
+    dec, sizes, dst = rx.decompress_blocks_v(out, o, [len(d) for d in datas], bs, params)
+    assert not dst.any() and all(x.tobytes() == d for x, d in zip(dec, datas))
+
+
 @pytest.mark.parametrize("params", [(8, 30, 32), (8, 22, 24), (8, 14, 16)])
 def test_wave_decoder_on_damaged_large_blocks(rx, params):
     """k_decode_wave (one block per wave, the model as a cumulative table across the lanes: redux_decode_wave.hpp) takes the
