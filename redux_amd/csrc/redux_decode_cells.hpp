@@ -53,9 +53,9 @@ typedef uint32_t cl_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int SB, int LANES, bool GLOBAL0>
 struct CellGeom {
-    static_assert(SB >= 1 && SB <= 12 && SB != 8, "8-bit symbols have k_decode_lock");
+    static_assert(SB >= 1 && SB <= 12, "symbol widths of the lock-step kernels"); // (8: blocks above 64 KiB, which k_decode_lock's u16 nodes do not hold)
     static_assert(!GLOBAL0 || SB > 8, "only the u16 bottom cells go to the workspace");
-    static constexpr bool     kU32       = SB < 8;             // node type
+    static constexpr bool     kU32       = SB <= 8;            // node type
     static constexpr int      kGroups    = (SB + 3) / 4;
     static constexpr int      kTopLevels = SB - 4 * (kGroups - 1);
     static constexpr uint32_t kCellBytes = kU32 ? 64u : 32u;
@@ -264,7 +264,7 @@ struct CellTree {
 template <int SB, int LANES, bool GLOBAL0, bool FIX = false>
 __global__ void __launch_bounds__(64) k_decode_cells(GenDecArgs a)
 {
-    static_assert(!FIX || SB < 8, "the fix-up variant is for the u32-node widths");
+    static_assert(!FIX || SB <= 8, "the fix-up variant is for the u32-node widths");
     typedef CellGeom<SB, LANES, GLOBAL0> G;
     __shared__ __attribute__((aligned(16))) uint32_t lds[G::kLdsBytes / 4];
     // One wave per SIMD, by construction ("placement"): a lock-step wave that shares its SIMD takes

@@ -27,7 +27,10 @@
 
 namespace redux {
 
-constexpr uint64_t kWaveDecMaxBlocks = 1024; // one wave per SIMD: beyond that the waves share SIMDs and the lock-step decoder wins
+#ifndef REDUX_WAVE_DEC_MAX_BLOCKS // (A/B builds set it)
+#define REDUX_WAVE_DEC_MAX_BLOCKS 1024
+#endif
+constexpr uint64_t kWaveDecMaxBlocks = REDUX_WAVE_DEC_MAX_BLOCKS; // one wave per SIMD: beyond that the waves share SIMDs and the lock-step decoder wins
 
 // The bit reader of a wave that decodes ONE stream (bitio/mod.rs:78-120): the stream comes in rows of 64 dwords -- lane l
 // loads dword l of the row, one coalesced request -- and lives in a register ACROSS the lanes; the next dword for the
@@ -153,6 +156,8 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
     // branch costs a lone wave ~35 cycles and every scalar instruction an issue slot, so the loop has no other exits.  (An
     // EOF step's garbage is harmless: its "symbol" is 256, which the update ignores, and nothing of it is committed.)
     double   rc_next = rcp[0]; // the reciprocal of step p + 1 is loaded during step p (a lone wave hides no latency by itself)
+    double   rcv     = 0.0;         // past the table: lane l holds the reciprocal of count 257 + rbase + l
+    uint32_t rbase   = 0xFFFFFF00u; // (no such base: the first step past the table computes its 64)
     uint32_t p       = 0;
     bool     eof = false, dry = false;
     // stream bits not pulled yet, as a 32-bit count-down (a block is below 4 GiB, so stream_bits < 2^35: the count-down is
@@ -165,8 +170,21 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
         for (;; p++) {
             const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
             double         rc  = rc_next;
-            if (__builtin_expect(nup >= a.rc_n, 0)) // past the table's window: computed as k_fill_rc computes an entry (rc_lookup)
-                rc = rc_lookup(rcp, 0, nup, 257u);
+            if (__builtin_expect(nup >= a.rc_n, 0)) {
+                // past the table's window: the reciprocals of 64 consecutive counts at a time, one per lane, each computed as
+                // k_fill_rc computes an entry (the correctly rounded quotient, biased up 4 ulp) -- ONE division sequence per 64
+                // steps -- and this step's picked out by two v_readlane (a division per step: 432.5 ns per symbol over a 4 MiB block, this: 427.7)
+                if (nup - rbase >= 64u) { // (wave-uniform)
+                    rbase          = nup & ~63u;
+                    const double r = 1.0 / (double)(257u + rbase + lane);
+                    rcv            = __longlong_as_double(__double_as_longlong(r) + 4);
+                }
+                const uint32_t       li = nup - rbase;
+                const unsigned long long rb = (unsigned long long)__double_as_longlong(rcv);
+                const uint32_t       lo_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rb, (int)li);
+                const uint32_t       hi_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rb >> 32), (int)li);
+                rc = __longlong_as_double((long long)(((unsigned long long)hi_ << 32) | lo_));
+            }
             {   // (the load is unconditional -- its index clamped into the table -- and nothing waits for it before the next step)
                 const uint32_t nx = p + 1 < a.nfreeze ? p + 1 : a.nfreeze;
                 rc_next           = rcp[nx < a.rc_n ? nx : a.rc_n];

@@ -188,6 +188,25 @@ static bool gen_decode_in_workspace(const redux_params *p, uint64_t nblocks)
     return p->symbol_bits >= 11;
 }
 static uint64_t gen_decode_tree_bytes(const redux_params *p) { return (1ull << (p->symbol_bits - 4)) * 32; }
+// 8-bit symbols in blocks above 64 KiB (which k_decode_lock's u16 nodes do not hold), in launches too big for one block per
+// wave (k_decode_wave): the cell decoder with u32 nodes -- 68 KiB of cells per wave, two waves per CU -- instead of k_decode's
+// per-lane control flow.  No block tables (the cell decoder takes blocks in order), blocks of at most 4 MiB (its reciprocal
+// table is indexed by the symbol number).
+static bool cells8_takes(const redux_params *p, uint32_t block_size, uint64_t nslots, bool table)
+{
+    // (nslots == 0: "a full grid", redux_decode_kernel_name)
+    return p->symbol_bits == 8 && p->code_bits <= 32 && block_size > 65536 && block_size <= (1u << 22) &&
+           (nslots == 0 || nslots > kWaveDecMaxBlocks) && !table;
+}
+static uint32_t cells8_rc_entries(const redux_params *p, uint32_t block_size)
+{
+    const uint64_t nfreeze = ((1ull << p->freq_bits) - 1) - 257;
+    return (uint32_t)((block_size < nfreeze ? block_size : nfreeze) + 1 + 32);
+}
+static bool cells8_needs_fixup(const redux_params *p, uint32_t block_size)
+{
+    return 257ull + cells8_rc_entries(p, block_size) - 33 > (1ull << 17) + 64;
+}
 
 static uint64_t slot_cap_for(const redux_params *p, uint32_t block_size)
 {
@@ -347,7 +366,7 @@ static uint32_t cu_count()
 // ---- which kernel a call runs: ONE decision, used by the launch code and reported by
 // redux_encode_kernel_name / redux_decode_kernel_name (bench.py's roofline.kernel) ------------
 enum class EncKernel { PairCb32, Pair, SingleU16, SingleU16Fixup, SingleU32, Gen, GenPair, Any, CoopCb32, Coop };
-enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Cells, CellsFixup, CellsWorkspace, Any, Wave, WaveFixup };
+enum class DecKernel { LockCb32, Lock, GenericU16, GenericU16Fixup, GenericU32, Cells, CellsFixup, CellsWorkspace, Cells8, Cells8Fixup, Any, Wave, WaveFixup };
 
 // 64 blocks per wave while 64 slots / 64 blocks stay within a 32-bit lane offset; otherwise
 // (giant blocks, whole-stream mode) one block per wave.
@@ -384,7 +403,7 @@ static EncKernel pick_encode_kernel(const Geometry &g, const redux_params *p, bo
 }
 
 // nslots: blocks (or table entries) of the launch; 0 = unknown (redux_decode_kernel_name: the full-grid choice)
-static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p, uint64_t nslots = 0, uint32_t block_size = 0)
+static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p, uint64_t nslots = 0, uint32_t block_size = 0, bool table = false)
 {
     if (g.gen) {
         if (gen_needs_fixup(p, block_size))
@@ -393,6 +412,8 @@ static DecKernel pick_decode_kernel(const Geometry &g, const redux_params *p, ui
     }
     if (g.any)
         return DecKernel::Any;
+    if (cells8_takes(p, block_size, nslots, table))
+        return cells8_needs_fixup(p, block_size) ? DecKernel::Cells8Fixup : DecKernel::Cells8;
     // blocks the lock-step decoder does not take (u32 counts, count >= 2^17: one block of any length above all,
     // redux_decompress) in a launch that leaves SIMDs idle: one block per wave, the model across the lanes
     // (redux_decode_wave.hpp).  (For u16 blocks it measures 28.9 ms per 64 KiB block against the lock-step decoder's 24.)
@@ -485,6 +506,8 @@ const char *redux_decode_kernel_name_n(const redux_params *p, const void *d_out,
                                                "k_decode_cells<10>", "k_decode_cells<11>", "k_decode_cells<12>"};
         return names[p->symbol_bits];
     }
+    case DecKernel::Cells8:
+    case DecKernel::Cells8Fixup: return "k_decode_cells<8> (u32 cells, blocks above 64 KiB, one wave per 64 blocks)";
     case DecKernel::Any: return "k_decode_any (general parameters, one lane per block)";
     case DecKernel::Wave:
     case DecKernel::WaveFixup: return "k_decode_wave (one block per wave, cumulative table across the lanes)";
@@ -923,7 +946,9 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
     if (g.any)
         return (nblocks ? nblocks : 1) * g.tree_bytes;
     // the reciprocal table, then room for the checked copy of a block table and its bitmap (redux_table.hpp)
-    return align_up((uint64_t)dec_rc_entries(g) * 8, 256) + align_up(nblocks * sizeof(redux_block), 256) + align_up(table_seen_words(nblocks) * 4, 256);
+    const uint64_t rc_n = cells8_takes(p, block_size, nblocks ? nblocks : 1, false) ? std::max<uint64_t>(cells8_rc_entries(p, block_size), dec_rc_entries(g))
+                                                                                  : dec_rc_entries(g);
+    return align_up(rc_n * 8, 256) + align_up(nblocks * sizeof(redux_block), 256) + align_up(table_seen_words(nblocks) * 4, 256);
 }
 
 // d_in_used (optional, u64[nblocks]): bytes of each stream the reader fetched; only
@@ -1019,6 +1044,32 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         HIP_TRY(hipGetLastError());
         return REDUX_OK;
     }
+    if (cells8_takes(p, block_size, nblocks, d_table != nullptr)) {
+        GenDecArgs ga;
+        ga.in         = (const uint8_t *)d_in;
+        ga.in_offsets = (const uint64_t *)d_in_offsets;
+        ga.nblocks    = nblocks;
+        ga.out        = (uint8_t *)d_out;
+        ga.out_sizes  = (uint32_t *)d_out_sizes;
+        ga.status     = (int32_t *)d_block_status;
+        ga.rc         = (const double *)d_workspace;
+        ga.trees      = nullptr;
+        ga.in_used    = (uint64_t *)d_in_used;
+        ga.block_size = block_size;
+        ga.nfreeze    = g.nfreeze;
+        ga.code_bits  = p->code_bits;
+        const uint32_t rc8 = cells8_rc_entries(p, block_size);
+        k_fill_rc<<<(rc8 + 255) / 256, 256, 0, s>>>((double *)d_workspace, rc8);
+        const uint32_t grid64 = (uint32_t)((nblocks + 63) / 64);
+        if (cells8_needs_fixup(p, block_size))
+            k_decode_cells<8, 64, false, true><<<grid64, 64, 0, s>>>(ga);
+        else
+            k_decode_cells<8, 64, false, false><<<grid64, 64, 0, s>>>(ga);
+        if (d_summary)
+            k_summarize<<<64, 256, 0, s>>>((const int32_t *)d_block_status, nblocks, (int32_t *)d_summary);
+        HIP_TRY(hipGetLastError());
+        return REDUX_OK;
+    }
     const uint32_t rc_n = dec_rc_entries(g);
     k_fill_rc<<<(rc_n + 255) / 256, 256, 0, s>>>((double *)d_workspace, rc_n);
     const uint32_t *table_failed = nullptr;
@@ -1072,6 +1123,8 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     case DecKernel::Cells:
     case DecKernel::CellsFixup:
     case DecKernel::CellsWorkspace:
+    case DecKernel::Cells8:
+    case DecKernel::Cells8Fixup:
     case DecKernel::Any: break; // handled above
     }
     if (d_summary) // (with a block table nblocks counts its entries: statuses are per block)

@@ -970,7 +970,11 @@ def test_kernel_names_follow_the_dispatch(rx):
     assert dec((8, 30, 32), 65536).startswith("k_decode_lock<true>")
     assert dec((8, 22, 24), 65536).startswith("k_decode_lock<false>")
     assert dec((8, 30, 32), 1001, 2).startswith("k_decode_lock<true>")
-    assert dec((8, 30, 32), 1 << 20).startswith("k_decode<false, true>")
+    assert dec((8, 30, 32), 1 << 20).startswith("k_decode_cells<8>")                     # blocks above 64 KiB on a full grid: u32 cells
+    assert dec((8, 30, 32), 1 << 23).startswith("k_decode<false, true>")                  # ... above 4 MiB: per-lane control flow
+    cp8 = _lib.Params(8, 30, 32)
+    name_n = lambda bs, nb: L.redux_decode_kernel_name_n(C.byref(cp8), None, bs, nb).decode()
+    assert name_n(1 << 20, 1024).startswith("k_decode_wave") and name_n(1 << 20, 1025).startswith("k_decode_cells<8>")
     assert enc((8, 3, 32), 0, 1, 1) == ""
 
 
@@ -1457,18 +1461,20 @@ def test_small_grid_kernels_code_long_blocks_in_windows(rx, params, bs, nfull):
     assert not dst.any() and all(x.tobytes() == d for x, d in zip(dec, datas))
 
 
-@pytest.mark.parametrize("params", [(8, 30, 32), (8, 22, 24), (8, 14, 16)])
-def test_wave_decoder_on_damaged_large_blocks(rx, params):
-    """k_decode_wave (one block per wave, the model as a cumulative table across the lanes: redux_decode_wave.hpp) takes the
-    blocks the lock-step decoder cannot -- capacities past 64 KiB -- in small launches.  Intact, bit-flipped, truncated and
-    over-long streams of 70,000 - 200,000 symbols, and garbage: status, decoded length and decoded bytes of every block
-    equal the CPU restatement's, at a capacity some of them overflow."""
-    rnd = np.random.default_rng(sum(params) + 5)
-    cap = 150_000
-    streams = [rnd.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (0, 1, 3, 4, 5, 17, 300, 4001)]  # garbage
+def _damaged_large_blocks(rx, params, cap, filler, kernel):
+    """Intact, bit-flipped, truncated and over-long streams of large blocks, and garbage, + `filler` short intact streams in
+    front of them (what decides which decoder the launch gets): status, decoded length and decoded bytes of every block
+    against the CPU restatement's, at a capacity some of them overflow."""
+    import ctypes as C
+    from redux_amd import _lib
+    rnd = np.random.default_rng(sum(params) + 5 + filler)
+    fill_src = [rnd.integers(0, 256, int(rnd.integers(0, 40)), dtype=np.uint8).tobytes() for _ in range(16)]
+    fill = [(src, ox.compress(src, params)[0]) for src in fill_src]
+    streams = [fill[i % 16][1] for i in range(filler)]
+    streams += [rnd.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (0, 1, 3, 4, 5, 17, 300, 4001)]  # garbage
     for i in range(20):
         kind = i % 5
-        n = int(rnd.integers(cap + 1, 200_000)) if kind == 4 else int(rnd.integers(70_000, 149_000))  # kind 4: more symbols than the capacity
+        n = int(rnd.integers(cap + 1, cap + 50_000)) if kind == 4 else int(rnd.integers(70_000, cap - 1000))  # kind 4: more symbols than the capacity
         src = (rnd.integers(0, 256, n, dtype=np.uint8) >> int(rnd.integers(0, 7))).tobytes()
         good, _ = ox.compress(src, params)
         b = bytearray(good)
@@ -1479,12 +1485,18 @@ def test_wave_decoder_on_damaged_large_blocks(rx, params):
         elif kind == 2:
             b += rnd.integers(0, 256, int(rnd.integers(1, 9)), dtype=np.uint8).tobytes()  # trailing bytes
         streams.append(bytes(b))                                                      # kinds 3, 4: intact (4: may overflow the capacity)
+    cp = _lib.Params(*params)
+    assert kernel in _lib.lib().redux_decode_kernel_name_n(C.byref(cp), None, cap, len(streams))
     offs = np.zeros(len(streams) + 1, dtype=np.uint64)
     offs[1:] = np.cumsum([len(x) for x in streams])
     dense = np.frombuffer(b"".join(streams), dtype=np.uint8)
     dec, sizes, status = rx.decompress_blocks(dense, offs, cap, params, check=False)
     seen = set()
     for b, stream in enumerate(streams):
+        if b < filler:
+            want = fill[b % 16][0]
+            assert int(status[b]) == 0 and int(sizes[b]) == len(want) and dec[b * cap: b * cap + len(want)].tobytes() == want, b
+            continue
         st, want = _oracle_decode_raw(stream, cap, params)
         st = 4 if st == 3 else st  # the oracle's writer fails with IoError where the block capacity ends
         seen.add(st)
@@ -1492,6 +1504,22 @@ def test_wave_decoder_on_damaged_large_blocks(rx, params):
         assert int(sizes[b]) == len(want), (b, len(stream), int(sizes[b]), len(want))
         assert dec[b * cap: b * cap + len(want)].tobytes() == want, (b, len(stream))
     assert {0, 1, 4} <= seen
+
+
+@pytest.mark.parametrize("params", [(8, 30, 32), (8, 22, 24), (8, 14, 16)])
+def test_wave_decoder_on_damaged_large_blocks(rx, params):
+    """k_decode_wave (one block per wave, the model as a cumulative table across the lanes: redux_decode_wave.hpp) takes the
+    blocks the lock-step decoder cannot -- capacities past 64 KiB -- in small launches."""
+    _damaged_large_blocks(rx, params, 150_000, 0, b"k_decode_wave")
+
+
+@pytest.mark.parametrize("params,cap", [((8, 30, 32), 150_000), ((8, 30, 32), 100_000), ((8, 22, 24), 150_000), ((8, 14, 16), 100_000), ((8, 16, 18), 150_000)])
+def test_cell_decoder_on_damaged_large_blocks(rx, params, cap):
+    """... and in launches of more than 1024 blocks they run on the cell decoder with u32 nodes (k_decode_cells<8>,
+    redux_decode_cells.hpp): lock-step, 64 blocks per wave -- its fix-up instance where the count can pass 2^17 (capacity
+    150,000 under a model that does not freeze before), the plain one otherwise (capacity 100,000; a model of 14 or 16 frequency
+    bits, which freezes inside the block)."""
+    _damaged_large_blocks(rx, params, cap, 1100, b"k_decode_cells<8>")
 
 
 def test_hostile_block_tables_are_rejected_on_the_device(rx):

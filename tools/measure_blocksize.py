@@ -16,13 +16,15 @@ from redux_amd import _lib  # noqa: E402
 total_mib = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 params = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (8, 30, 32)
 sizes_kib = [int(x) for x in sys.argv[3:]] or [16, 64, 128, 256, 1024, 4096]
-n = total_mib << 20
-d_in = rx.gen_zipf(n)
+total_bytes = total_mib << 20
+d_all = rx.gen_zipf(total_bytes)
 L = _lib.lib()
 cp = _lib.Params(*params)
 for kib in sizes_kib:
     block = kib << 10
-    nb = n // block
+    nb = total_bytes // block
+    n = nb * block
+    d_in = d_all[:n]
     enc = rx.DeviceEncoder(params, block, n)
     dec = rx.DeviceDecoder(params, block, nb)
     out, offs, st, sm = enc.encode(d_in)

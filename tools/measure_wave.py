@@ -14,7 +14,11 @@ import redux_amd as rx  # noqa: E402
 from redux_amd import _lib  # noqa: E402
 
 P = (8, 30, 32)
-for kind, bs, nb in (("iid", 1 << 20, 1), ("zipf", 1 << 20, 1), ("iid", 1 << 20, 16), ("iid", 131072, 62), ("zipf", 262144, 256)):
+SHAPES = (("iid", 1 << 20, 1), ("zipf", 1 << 20, 1), ("iid", 1 << 20, 16), ("iid", 131072, 62), ("zipf", 262144, 256),
+          ("zipf", 4 << 20, 1))  # (the last one: three quarters of it past the reciprocal table's window of 2^20 entries)
+if len(sys.argv) > 1:  # tools/measure_wave.py zipf,4194304,1 ...
+    SHAPES = tuple((a.split(",")[0], int(a.split(",")[1]), int(a.split(",")[2])) for a in sys.argv[1:])
+for kind, bs, nb in SHAPES:
     n = bs * nb
     d_in = (rx.gen_iid if kind == "iid" else rx.gen_zipf)(n)
     enc = rx.DeviceEncoder(P, bs, n)
