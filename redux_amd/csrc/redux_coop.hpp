@@ -38,25 +38,47 @@ constexpr uint64_t kCoopMaxPairBytes = 3ull << 29; // ... and never more than 1.
 constexpr uint32_t kCoopMinBlock  = 1024; // shorter blocks: the per-block set-up (scan, tree build) outweighs the model
 constexpr uint32_t kCoopSlack     = 64;   // symbols of slack behind a group's pairs (the chain wave prefetches unclamped)
 // Blocks above 64 KiB are coded in windows (EncArgs::win0): the pairs of one window of all blocks take at most this much ...
-constexpr uint64_t kCoopWindowBytes = 512ull << 20;
-constexpr uint64_t kCoopWindowMax   = 1ull << 20; // ... and a window is at most this many symbols (8 MiB of pairs and of reciprocals per block)
+#ifndef REDUX_COOP_WINDOW_MIB // (A/B builds set these)
+#define REDUX_COOP_WINDOW_MIB 1408
+#endif
+#ifndef REDUX_COOP_MAX_LARGE_BLOCKS
+#define REDUX_COOP_MAX_LARGE_BLOCKS 24576
+#endif
+constexpr uint64_t kCoopWindowBytes = (uint64_t)REDUX_COOP_WINDOW_MIB << 20;
+constexpr uint64_t kCoopMaxLargeBlocks = REDUX_COOP_MAX_LARGE_BLOCKS; // slots of a launch of blocks above 64 KiB
+constexpr uint64_t kCoopWindowMax   = 65504;      // ... and a window is at most this many symbols: what a u16 tree node counts (k_coop_model)
 
-// inclusive sum over the wave's lanes 0 .. lane
+// pairs of a block coded in windows: one window + slack, an even number of pairs (16-byte loads)
+__host__ __device__ __forceinline__ uint64_t coop_block_pitch(uint32_t winlen) { return ((uint64_t)winlen + kCoopSlack + 1) & ~1ull; }
+
+// inclusive sum over the wave's lanes 0 .. lane.  DPP: Hillis-Steele inside each row of 16 lanes (row_shr:1, 2, 4, 8; a lane
+// whose source falls outside its row adds 0), then lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15), then lane 31 into
+// rows 2 and 3 (row_bcast:31): six VALU additions.  (__shfl_up is a ds_bpermute -- an LDS round trip -- per step: six dependent
+// ones per scan, 255 scans per block and window, on a wave that has nothing else to run: ~60 of the ~100 us a block-window
+// took, which is what bounded launches of many large blocks once they were coded in windows.)
 __device__ __forceinline__ uint32_t coop_wave_scan(uint32_t v, uint32_t lane)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t w = __shfl_up(v, o);
-        v += lane >= (uint32_t)o ? w : 0u;
-    }
+    (void)lane;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
     return v;
 }
 
-template <bool U16>
+// WINB: the block is coded in windows (blocks above 64 KiB).  The lanes' trees still hold u16 nodes -- they count the symbols
+// of THIS window only, at most kCoopWindowMax of them --, and what the windows before it counted comes from a table of the
+// block in LDS: bcum[s] = the symbols < s among them (cbase: the counts themselves, carried in the workspace).  32 KiB + 1 KiB
+// per block: four blocks per CU in flight, as for blocks of up to 64 KiB (u32 nodes: two).
+template <bool WINB>
 __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
 {
+    constexpr bool U16 = true;
     typedef Tree<U16> TreeT;
-    __shared__ uint32_t lds[TreeT::kDwords];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[TreeT::kDwords + (WINB ? 260 : 0)];
+    uint32_t *const bcum = lds + TreeT::kDwords; // WINB: 257 entries
     const uint32_t lane = threadIdx.x;
     const uint64_t ent  = blockIdx.x; // the slot: lane ent & 63 of chain wave ent >> 6
     const uint8_t *src;
@@ -75,7 +97,7 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
         len = rem < a.block_size ? (uint32_t)rem : a.block_size;
     }
     // this launch's window of the block: symbols [w0, w0 + lenw)
-    const uint32_t w0 = a.win0;
+    const uint32_t w0 = WINB ? a.win0 : 0u;
     if (len <= w0)
         return;
     const uint32_t lenw = len - w0 < a.winlen ? len - w0 : a.winlen;
@@ -116,45 +138,73 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
     // ---- 2. row r: counts of symbol r - 1 in the segments BEFORE this lane's (exclusive scan over the lanes) -- and, when
     //         the block is coded in windows, in the windows before this one: cbase row r of the block, lane l holding
     //         rows 4l .. 4l + 3 of it while the scan runs, updated with this window's totals for the next one
-    uint4 *basep = (!U16 && a.cbase) ? reinterpret_cast<uint4 *>(a.cbase + ent * 256) + lane : nullptr; // (wave-uniform null-ness)
-    uint4  bq    = (basep && w0) ? *basep : make_uint4(0, 0, 0, 0);
-    for (uint32_t r4 = 0; r4 < 64; r4++) {
+    uint4 *basep = WINB ? reinterpret_cast<uint4 *>(a.cbase + ent * 256) + lane : nullptr;
+    uint4  bq    = (WINB && w0) ? *basep : make_uint4(0, 0, 0, 0);
+    if (WINB) { // bcum[r] = rows 1 .. r of the base counts (row r = symbol r - 1), r = 0 .. 255; bcum[256] = 0: cum(256) is derived
+        const uint32_t p0 = lane ? bq.x : 0u, p1 = p0 + bq.y, p2 = p1 + bq.z, p3 = p2 + bq.w;
+        const uint32_t ex = coop_wave_scan(p3, lane) - p3;
+        reinterpret_cast<uint4 *>(bcum)[lane] = make_uint4(ex + p0, ex + p1, ex + p2, ex + p3);
+        if (lane == 0)
+            bcum[256] = 0;
+    }
+    for (uint32_t r4 = 0; r4 < 64; r4++) { // four rows per turn: their LDS reads, scans and writes overlap (a lone wave hides nothing by itself)
         const uint32_t bw[4] = {bq.x, bq.y, bq.z, bq.w};
         uint32_t       nw[4] = {bq.x, bq.y, bq.z, bq.w};
+        uint32_t       v[4], incl[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            v[k] = T.node(((4 * r4 + k) << TreeT::kShift) | T.L); // (row 0 is read and scanned too; nothing uses it)
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            incl[k] = coop_wave_scan(v[k], lane);
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
             const uint32_t r = 4 * r4 + k;
             if (r == 0)
                 continue;
-            const uint32_t v    = T.node((r << TreeT::kShift) | T.L);
-            const uint32_t incl = coop_wave_scan(v, lane);
-            const uint32_t br   = basep ? (uint32_t)__shfl((int)bw[k], (int)r4) : 0u;
-            char          *cell = reinterpret_cast<char *>(lds) + ((r << TreeT::kShift) | T.L);
-            if (U16)
-                *reinterpret_cast<uint16_t *>(cell + 2 * (lane >> 5)) = (uint16_t)(incl - v);
-            else
-                *reinterpret_cast<uint32_t *>(cell) = incl - v + br;
-            if (basep) {
-                const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
+            // (r4 is wave-uniform: v_readlane, not a cross-lane LDS operation)
+            char *cell = reinterpret_cast<char *>(lds) + ((r << TreeT::kShift) | T.L);
+            *reinterpret_cast<uint16_t *>(cell + 2 * (lane >> 5)) = (uint16_t)(incl[k] - v[k]);
+            if (WINB) { // this window's count of the symbol joins the base counts for the next window
+                const uint32_t br  = (uint32_t)__builtin_amdgcn_readlane((int)bw[k], (int)r4);
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl[k], 63);
                 nw[k] = lane == r4 ? br + tot : nw[k];
             }
         }
         bq = make_uint4(nw[0], nw[1], nw[2], nw[3]);
     }
-    if (basep)
+    if (WINB)
         *basep = bq;
     __syncthreads();
     // ---- 3. the Fenwick form in place (node i also covers node i - lowbit(i) + ... : adaptive_tree.rs:43-59): d[i] is
     //         the number of increments node i has received after the symbols before this segment
-    for (uint32_t i = 1; i < 256; i++) {
-        const uint32_t j = i + (i & (0u - i));
-        if (j < 256) {
-            const uint32_t v = T.node((i << TreeT::kShift) | T.L);
-            T.add((j << TreeT::kShift) | T.L, v << T.hsh);
+    //         Level by level -- the nodes (2k + 1) << b are complete once the levels below b have been pushed up, and
+    //         independent of each other --, eight nodes in flight at a time (in index order every read waits for the atomic
+    //         before it: 255 dependent LDS round trips)
+#pragma unroll
+    for (int b = 0; b < 7; b++) {
+        const uint32_t n = 128u >> b; // nodes of this level
+        for (uint32_t k0 = 0; k0 < n; k0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                const uint32_t k = k0 + q, i = (2 * k + 1) << b;
+                v[q] = k < n ? T.node((i << TreeT::kShift) | T.L) : 0u;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                const uint32_t k = k0 + q, j = (2 * k + 2) << b;
+                if (k < n && j < 256)
+                    T.add((j << TreeT::kShift) | T.L, v[q] << T.hsh);
+            }
         }
     }
     // ---- 4. query + update over the segment (adaptive_tree.rs:63-92), pairs out
-    uint2 *pg = pairs + ((ent >> 6) * ((uint64_t)a.winlen + kCoopSlack)) * a.pair_width + (ent & 63);
+    // blocks of up to 64 KiB: symbol-major rows of 64 lanes per group; blocks coded in windows: block-major, a
+    // block's window contiguous -- a lane then completes the 128-byte lines it writes by itself (sixteen consecutive stores)
+    // instead of sharing each line with fifteen other workgroups on other XCDs, whose L2s each wrote their 8 bytes of it back
+    uint2         *pg = WINB ? pairs + ent * coop_block_pitch(a.winlen) : pairs + ((ent >> 6) * ((uint64_t)a.winlen + kCoopSlack)) * 64 + (ent & 63);
+    const uint32_t pw = WINB ? 1u : 64u;
     {
         uint4 nx = npieces ? piece(0) : make_uint4(0, 0, 0, 0);
         for (uint32_t k = 0; k < maxpieces; k++) {
@@ -171,8 +221,12 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
                     const uint32_t nup = q < a.nfreeze ? q : a.nfreeze;     // updates before this one
                     uint32_t       lo, hi;
                     // (the update of a block's last symbol is unobservable and skipped: u16 nodes, Tree)
-                    T.template get_frequency<true>(s, nup, q < a.nfreeze && (!U16 || q + 1 != len), lo, hi);
-                    pg[(uint64_t)(q - w0) * a.pair_width] = make_uint2(lo, hi);
+                    T.template get_frequency<true>(s, nup, q < a.nfreeze && q + 1 != len, lo, hi);
+                    if (WINB) { // (two adjacent entries)
+                        lo += bcum[s];
+                        hi += bcum[s + 1];
+                    }
+                    pg[(uint64_t)(q - w0) * pw] = make_uint2(lo, hi);
                 }
             }
         }
@@ -348,23 +402,23 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
         // a lane without a block runs the lock-step part on a copy of the wave's first live block (valid pairs: its own
         // column of the workspace was never written) and sends empty messages after it
         const uint32_t col  = live ? lane : (uint32_t)__builtin_ctzll(lives);
-        const uint32_t pw   = a.pair_width; // lanes per row of the pairs: 64, or the number of blocks of a launch of fewer
-        const uint64_t gcol = (uint64_t)blockIdx.x * ((uint64_t)a.winlen + kCoopSlack) * pw;
-        const uint2   *pg   = pairs + gcol + col;
+        // the pairs: rows of 64 lanes per symbol and group (blocks of up to 64 KiB), or block-major (WIN: k_coop_model)
+        const uint2 *pg = WIN ? pairs + (blk0 + col) * coop_block_pitch(a.winlen)
+                              : pairs + (uint64_t)blockIdx.x * ((uint64_t)a.winlen + kCoopSlack) * 64 + col;
         auto load16 = [&](uint2 (&d)[16], uint32_t p) { // (up to 47 symbols past the last chunk: inside the slack)
-            const uint2 *q = pg + (uint64_t)p * pw;
-            if (__builtin_expect(pw == 64, 1)) { // (wave-uniform) whole groups: the row offsets are immediates of the sixteen loads
+            if (WIN) { // a chunk is one 128-byte line of the lane's block (the pitch is even, p a multiple of 16)
+                const uint4 *q = reinterpret_cast<const uint4 *>(pg + p);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint4 t = q[i];
+                    d[2 * i]      = make_uint2(t.x, t.y);
+                    d[2 * i + 1]  = make_uint2(t.z, t.w);
+                }
+            } else { // whole groups: the row offsets are immediates of the sixteen loads
+                const uint2 *q = pg + (uint64_t)p * 64;
 #pragma unroll
                 for (int i = 0; i < 16; i++)
                     d[i] = q[i * 64];
-            } else if (pw == 1) { // one block of any length (redux_compress): its pairs are contiguous
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                    d[i] = q[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                    d[i] = q[(uint32_t)i * pw];
             }
         };
         ChainState X;

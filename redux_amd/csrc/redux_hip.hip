@@ -280,12 +280,12 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     // a grid that leaves most SIMDs idle: the model by 64 lanes per block, the chain by one.  One block of any length --
     // redux_compress, the literal redux::compress -- is such a grid.  The pairs are rows of pair_width lanes (64, or the
     // number of blocks when there are fewer and they are large), block_size + slack rows per group of 64 blocks.
-    g.pair_width = (g.nblocks < 64 && !g.u16) ? (uint32_t)g.nblocks : 64u; // (large blocks only: a constant row stride is faster to address)
+    g.pair_width = g.u16 ? 64u : 1u; // blocks of up to 64 KiB: rows of 64 lanes per symbol; larger ones: block-major (k_coop_model)
     // Blocks of up to 64 KiB: the pairs of whole blocks (8 bytes per input byte).  Larger blocks -- one stream of any length
     // above all -- are coded in windows, one (model, chain) pair of launches per window, so that the pairs area and the
     // reciprocal table hold one window whatever the block length: the largest window whose pairs fit kCoopWindowBytes, at most
     // kCoopWindowMax symbols, the windows together covering block_size + 1 symbols (the last one holds a full block's EOF).
-    const uint64_t lanes_total = (g.nblocks + 63) / 64 * g.pair_width;
+    const uint64_t lanes_total = g.u16 ? (g.nblocks + 63) / 64 * 64 : g.nblocks;
     g.coop_win  = block_size + 1;
     g.coop_nwin = 1;
     if (!g.u16) {
@@ -297,11 +297,11 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
             g.coop_win  = (uint32_t)((((uint64_t)block_size + 1 + g.coop_nwin - 1) / g.coop_nwin + 31) & ~31ull);
         }
     }
-    const uint64_t pair_bytes = lanes_total * ((uint64_t)g.coop_win + kCoopSlack) * 8;
+    const uint64_t pair_bytes = (g.u16 ? lanes_total * ((uint64_t)g.coop_win + kCoopSlack) : lanes_total * coop_block_pitch(g.coop_win)) * 8;
     // fewer than 64 large blocks on the small-grid kernels: linear slots, one per block (a row-major group area is 64 slots
     // big whatever the number of blocks: 230 MiB to code one 3 MiB stream); a lane addresses its slot with 32-bit offsets
     const bool linear = g.nblocks < 64 && !g.u16;
-    g.coop = allow_coop && !static_model && !g.any && !g.gen && g.nblocks <= kCoopMaxBlocks && block_size >= kCoopMinBlock &&
+    g.coop = allow_coop && !static_model && !g.any && !g.gen && g.nblocks <= (g.u16 ? kCoopMaxBlocks : kCoopMaxLargeBlocks) && block_size >= kCoopMinBlock &&
              (linear ? g.nblocks : 64ull) * g.slot_bytes < (1ull << 32) && pair_bytes <= kCoopMaxPairBytes;
     if (g.coop) // the reciprocals of one window (+ what the chain wave reads ahead)
         g.rc_n = g.coop_win + 64;
@@ -320,7 +320,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.off_seen  = g.off_table + align_up(g.nblocks * sizeof(redux_block), 256);
     // small-grid kernels, blocks coded in windows: 8 words of coder state + 256 symbol counts per block, carried between windows
     g.off_cstate = g.off_seen + align_up(table_seen_words(g.nblocks) * 4, 256);
-    g.off_pairs  = g.off_cstate + ((g.coop && g.coop_nwin > 1) ? align_up(g.nblocks * (8 + 256) * 4, 256) : 0);
+    g.off_pairs  = g.off_cstate + ((g.coop && !g.u16) ? align_up(g.nblocks * (8 + 256) * 4, 256) : 0);
     g.total = g.off_pairs + (g.coop ? pair_bytes : 0);
     return g;
 }
@@ -683,7 +683,7 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
             memcpy(&a.rc_frozen, &u, 8);
         }
         a.winlen = g.coop_win;
-        a.cstate = g.coop_nwin > 1 ? (uint32_t *)(ws + g.off_cstate) : nullptr;
+        a.cstate = !g.u16 ? (uint32_t *)(ws + g.off_cstate) : nullptr;
         a.cbase  = a.cstate ? a.cstate + g.nblocks * 8 : nullptr;
         // the longest block of the launch: its EOF symbol (symbol number `length`) is the last one coded
         const uint64_t longest = d_table ? block_size : (in_len < block_size ? in_len : block_size);
@@ -691,10 +691,10 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
             a.win0 = w * g.coop_win;
             if (w) // (the first window's table was filled above)
                 k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)(ws + g.off_rc), g.rc_n, 257u + a.win0);
-            if (g.u16)
-                k_coop_model<true><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
-            else
+            if (g.u16) // whole blocks / one window of larger ones
                 k_coop_model<false><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
+            else
+                k_coop_model<true><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
             if (g.coop_linear) {
                 if (g.fixup) {
                     if (cb32) k_coop_chain<true, true, true><<<cgrid, 128, 0, s>>>(a, pairs);

@@ -952,7 +952,8 @@ def test_kernel_names_follow_the_dispatch(rx):
     assert enc((8, 30, 32), 0, 1 << 30, 65536).startswith("k_encode_pair<false, true>")
     assert enc((8, 14, 16), 0, 1 << 30, 65536).startswith("k_encode_pair<false, false>")
     assert enc((8, 30, 32), 4, 1 << 30, 65536).startswith("k_encode<true, false>")     # unaligned input
-    assert enc((8, 30, 32), 0, 1 << 32, 1 << 20).startswith("k_encode<false, true>")    # u32 tree
+    assert enc((8, 30, 32), 0, 1 << 35, 1 << 20).startswith("k_encode<false, true>")    # u32 tree: more than 24,576 blocks above 64 KiB
+    assert enc((8, 30, 32), 0, 1 << 32, 1 << 20).startswith("k_coop_model")             # ... up to there: coded in windows by the small-grid kernels
     assert enc((8, 30, 32), 0, 1 << 20, 1 << 20).startswith("k_coop_model")             # one block of any length: redux_compress
     assert enc((8, 30, 32), 0, 62 << 16, 65536).startswith("k_coop_model")              # a small launch
     assert enc((12, 14, 16), 0, 1 << 20, 65536).startswith("k_encode_gen_pair<12>")
@@ -1403,8 +1404,7 @@ def test_small_grid_kernels_on_large_blocks(rx):
 
 def _coop_window(nentries, block_size):
     """geometry() of redux_hip.hip: the window (symbols) the small-launch kernels code a launch of large blocks in."""
-    lanes = nentries if nentries < 64 else (nentries + 63) // 64 * 64
-    w = max(4096, min(1 << 20, (512 << 20) // (8 * lanes)))
+    w = max(4096, min(65504, (1408 << 20) // (8 * nentries)))
     if w >= block_size + 1:
         return block_size + 1, 1
     nwin = (block_size + 1 + w - 1) // w
@@ -1442,8 +1442,8 @@ def test_small_grid_kernels_code_long_blocks_in_windows(rx, params, bs, nfull):
         win = win2
     assert win2 == win and nwin >= 2, (win, win2, nwin)
     assert b"k_coop_model" in L.redux_encode_kernel_name(C.byref(cp), None, ne * bs, bs)
-    # (the slots, and at most 512 MiB of pairs + change: whole blocks would take 8 bytes of pairs per input byte of every entry)
-    assert L.redux_encode_workspace_bytes(C.byref(cp), ne * bs, bs) < (ne + 65) * (L.redux_encode_slot_bytes(C.byref(cp), bs) + 256) + (600 << 20)
+    # (the slots, and one window of pairs per entry + change: whole blocks would take 8 bytes of pairs per input byte of every entry)
+    assert L.redux_encode_workspace_bytes(C.byref(cp), ne * bs, bs) < (ne + 65) * (L.redux_encode_slot_bytes(C.byref(cp), bs) + 256) + ne * 66000 * 8 + (8 << 20)
     text = open(os.path.join(GOLDEN, "corpora", "large", "world192.txt"), "rb").read()
     datas = []
     for i, n in enumerate(lens):
