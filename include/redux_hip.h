@@ -78,6 +78,11 @@ uint64_t redux_block_count(uint64_t in_len, uint32_t block_size); /* max(1, ceil
 uint64_t redux_encode_slot_bytes(const redux_params *p, uint32_t block_size);
 /* Dense-output capacity that always suffices: block_count * slot_bytes. */
 uint64_t redux_encode_bound(const redux_params *p, uint64_t in_len, uint32_t block_size);
+/* Workspace of an encode call on the device: the blocks' slots, the reciprocal table and -- for launches the small-grid
+ * kernels take -- the (low, high) pairs: 8 bytes per input byte for at most 2048 blocks of up to 64 KiB; for at most 24,576
+ * blocks above 64 KiB (one block of any length included: redux_compress) ONE window of at most 65,504 symbols per block,
+ * at most 1408 MiB in all, because such blocks are coded window by window: the workspace of a long stream is its slot
+ * (9/8 of its length) + 1 MiB, whatever its length. */
 uint64_t redux_encode_workspace_bytes(const redux_params *p, uint64_t in_len, uint32_t block_size);
 uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, uint32_t block_size);
 
@@ -288,8 +293,9 @@ const char *redux_source_hash(void);
  * roofline.kernel) instead of assuming the fast path was taken. */
 const char *redux_encode_kernel_name(const redux_params *p, const void *d_in, uint64_t in_len, uint32_t block_size);
 const char *redux_decode_kernel_name(const redux_params *p, const void *d_out, uint32_t block_size);
-/* The decoder also depends on the SIZE of the launch (blocks the lock-step decoder does not take run one per wave in
- * launches of at most 1024 blocks, k_decode_wave; 11- and 12-bit symbols keep their bottom tree cells in LDS on small grids):
+/* The decoder also depends on the SIZE of the launch (blocks the lock-step decoder does not take -- above 64 KiB -- run one
+ * per wave in launches of at most 1024 blocks, k_decode_wave, and on the cell decoder with u32 nodes, k_decode_cells<8>, in
+ * larger ones; 11- and 12-bit symbols keep their bottom tree cells in LDS on small grids):
  * nblocks = blocks (or table entries) of the launch; 0 = a grid that fills the chip, which is what
  * redux_decode_kernel_name answers for. */
 const char *redux_decode_kernel_name_n(const redux_params *p, const void *d_out, uint32_t block_size, uint64_t nblocks);

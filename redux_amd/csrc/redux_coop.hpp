@@ -1,9 +1,10 @@
 // redux_hip -- small launches: the model of a block computed by 64 lanes, its interval chain by one.
 //
-//   k_coop_model<U16>          one WAVE per block: lane j runs AdaptiveTreeModel over the j-th 64th of the block, starting
-//                              from the counts of everything before it, and leaves every symbol's (low, high) in the
-//                              workspace (u16 nodes for blocks of up to 64 KiB, u32 nodes beyond)
-//   k_coop_chain<CB32, FIXUP>  one LANE per block, 64 blocks per workgroup of TWO waves: the interval half of
+//   k_coop_model<WINB>         one WAVE per block: lane j runs AdaptiveTreeModel over the j-th 64th of the block (of the
+//                              block's current window: WINB), starting from the counts of everything before it, and leaves
+//                              every symbol's (low, high) in the workspace
+//   k_coop_chain<CB32, FIXUP, LINEAR, WIN>
+//                              one LANE per block, 64 blocks per workgroup of TWO waves: the interval half of
 //                              compress_symbol (chain wave) and its bit-writer half (emit wave) over those pairs
 //
 // Why: with 64 blocks per wave a launch of n blocks keeps n / 64 SIMDs busy; below ~4096 blocks most of the chip idles
@@ -12,14 +13,17 @@
 // not on the coder's state: counts are prefix statistics of the input and parallelise exactly.  Lane j histograms its
 // segment, an exclusive scan across the lanes gives every segment its starting counts, each lane builds the Fenwick form
 // of those and then runs the ordinary query + update over its 1/64th.  Only codec.rs:55-60's chain (low, high depend on
-// the previous symbol's) stays serial: 27 instructions per symbol on a wave that does nothing else (5.0 ms per 64 KiB
-// block against 9.6 ms; one block of any length -- redux_compress, the literal redux::compress -- 3 -> 10 MB/s).
+// the previous symbol's) stays serial: 27 instructions per symbol on a wave that does nothing else (4.9 ms per 64 KiB
+// block against 9.6 ms; one block of any length -- redux_compress, the literal redux::compress -- 3 -> 9.5-13 MB/s).
 //
-// The pairs are stored symbol-major per group of 64 blocks, pairs[(group * (block_size + slack) + i) * width + lane] with
-// width = 64 (or the number of blocks when they are fewer and large), so the chain wave reads one contiguous row per
-// symbol.  Chosen by geometry() (redux_hip.hip) for launches of at most kCoopMaxBlocks slots whose pairs fit
-// kCoopMaxPairBytes, a model that freezes inside a block included; results are the same bytes as every other kernel's
-// (tests/test_gpu_parity.py: the corpus, batch, whole-stream and hand-made-table tests run on it).
+// Blocks of up to 64 KiB (launches of at most kCoopMaxBlocks slots whose pairs fit kCoopMaxPairBytes): whole blocks, the
+// pairs symbol-major per group of 64 blocks, pairs[(group * (block_size + 1 + slack) + i) * 64 + lane]: the chain wave reads
+// one contiguous row per symbol.  Blocks ABOVE 64 KiB (launches of at most kCoopMaxLargeBlocks): window by window -- one
+// k_fill_rc_from + k_coop_model<true> + k_coop_chain<.., WIN> per window of at most kCoopWindowMax symbols of every block
+// (EncArgs::win0, winlen; the loop is in redux_hip.hip) --, the pairs block-major, pairs[block * pitch + i - win0]; coder
+// state and symbol counts of a block travel in the workspace (cstate, cbase), so the pairs area and the reciprocal table
+// hold one window whatever the block length.  A model that freezes inside a block included; results are the same bytes as
+// every other kernel's (tests/test_gpu_parity.py: the corpus, batch, whole-stream, hand-made-table and windows tests).
 //
 // Included by redux_hip.hip (one translation unit).
 #pragma once

@@ -278,8 +278,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
         g.tree_bytes = align_up(((1ull << p->symbol_bits) + 2) * 4, 256);
     }
     // a grid that leaves most SIMDs idle: the model by 64 lanes per block, the chain by one.  One block of any length --
-    // redux_compress, the literal redux::compress -- is such a grid.  The pairs are rows of pair_width lanes (64, or the
-    // number of blocks when there are fewer and they are large), block_size + slack rows per group of 64 blocks.
+    // redux_compress, the literal redux::compress -- is such a grid (redux_coop.hpp).
     g.pair_width = g.u16 ? 64u : 1u; // blocks of up to 64 KiB: rows of 64 lanes per symbol; larger ones: block-major (k_coop_model)
     // Blocks of up to 64 KiB: the pairs of whole blocks (8 bytes per input byte).  Larger blocks -- one stream of any length
     // above all -- are coded in windows, one (model, chain) pair of launches per window, so that the pairs area and the

@@ -25,6 +25,8 @@ timeout -k 10 300 bash tools/prof_small.sh $TAG > $OUT/prof_small.txt 2>&1
 for nb in 4096 16384 65536; do timeout -k 10 400 python tools/measure_gen.py $nb >> $OUT/gen.txt 2>&1; done; tail -3 $OUT/gen.txt
 timeout -k 10 400 python tools/measure_gen.py 65536 1,10,16 2,10,16 4,10,16 6,26,32 7,25,32 9,23,32 10,22,32 12,14,16 >> $OUT/gen.txt 2>&1; tail -1 $OUT/gen.txt
 timeout -k 10 300 python tools/measure_wave.py > $OUT/wave.txt 2>&1; tail -2 $OUT/wave.txt
+timeout -k 10 300 python tools/measure_blocksize.py 2048 8,30,32 16 64 96 128 256 512 1024 2048 4096 > $OUT/blocksize.txt 2>&1; tail -1 $OUT/blocksize.txt
+timeout -k 10 200 python tools/big_stream.py 200000000 > $OUT/big_stream.txt 2>&1; tail -2 $OUT/big_stream.txt
 timeout -k 10 300 python tools/soak_cells.py 150 41 > $OUT/soak.txt 2>&1; tail -1 $OUT/soak.txt
 timeout -k 10 300 python tools/measure_static.py >> $OUT/static.txt 2>&1; tail -1 $OUT/static.txt
 timeout -k 10 500 python tools/corpus_table.py --batch > $OUT/corpus_batch.txt 2>&1
