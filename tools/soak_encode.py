@@ -46,9 +46,15 @@ t_end = time.time() + budget
 it = blocks = 0
 while time.time() < t_end:
     params = WIDTHS[rng.integers(0, len(WIDTHS))]
-    big = len(sys.argv) > 3 and sys.argv[3] == "big"  # blocks beyond 64 KiB: u32 trees, the one-wave kernels
-    bs = int(rng.choice([100000, 131072, 262144, 70001])) if big else int(rng.choice([48, 1000, 4096, 16384, 65536]))
+    # big: blocks beyond 64 KiB: the small-grid kernels window by window (linear slots below 64 blocks, group areas from there),
+    # k_decode_wave up to 1024 blocks and k_decode_cells<8> beyond
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    bs = int(rng.choice([100000, 131072, 262144, 70001, 1500000, 65504 * 2, 65504 * 3 - 1])) if big else int(rng.choice([48, 1000, 4096, 16384, 65536]))
     nb = int(rng.integers(1, 140)) if big else int(rng.integers(1, 400)) if bs >= 16384 else int(rng.integers(1, 3000))
+    if big and bs >= 1000000:
+        nb = int(rng.integers(1, 8))
+    elif big and bs < 140000 and rng.random() < 0.15:
+        nb = int(rng.integers(1025, 1400))
     n = max(0, nb * bs - int(rng.integers(0, bs)))
     host = np.ascontiguousarray(make(n) if n else np.zeros(0, dtype=np.uint8))
     n = int(host.size)  # (a generator may return fewer bytes than asked)
