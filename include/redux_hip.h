@@ -80,9 +80,9 @@ uint64_t redux_encode_slot_bytes(const redux_params *p, uint32_t block_size);
 uint64_t redux_encode_bound(const redux_params *p, uint64_t in_len, uint32_t block_size);
 /* Workspace of an encode call on the device: the blocks' slots, the reciprocal table and -- for launches the small-grid
  * kernels take -- the (low, high) pairs: 8 bytes per input byte for at most 2048 blocks of up to 64 KiB; for at most 24,576
- * blocks above 64 KiB (one block of any length included: redux_compress) ONE window of at most 65,504 symbols per block,
- * at most 1408 MiB in all, because such blocks are coded window by window: the workspace of a long stream is its slot
- * (9/8 of its length) + 1 MiB, whatever its length. */
+ * blocks above 64 KiB (one block of any length included: redux_compress) TWO windows of at most 65,504 symbols per block
+ * (1 MiB), at most 2816 MiB in all, because such blocks are coded window by window, the model of one window next to the
+ * coder of the one before: the workspace of a long stream is its slot (9/8 of its length) + 2 MiB, whatever its length. */
 uint64_t redux_encode_workspace_bytes(const redux_params *p, uint64_t in_len, uint32_t block_size);
 uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, uint32_t block_size);
 

@@ -38,12 +38,12 @@
 namespace redux {
 
 constexpr uint64_t kCoopMaxBlocks = 2048; // slots, idle table entries included (the pairs take 8 bytes per input byte of workspace: 1 GiB at 2048 x 64 KiB)
-constexpr uint64_t kCoopMaxPairBytes = 3ull << 29; // ... and never more than 1.5 GiB
+constexpr uint64_t kCoopMaxPairBytes = 3ull << 29; // ... and never more than 1.5 GiB (blocks of up to 64 KiB: whole blocks of pairs)
 constexpr uint32_t kCoopMinBlock  = 1024; // shorter blocks: the per-block set-up (scan, tree build) outweighs the model
 constexpr uint32_t kCoopSlack     = 64;   // symbols of slack behind a group's pairs (the chain wave prefetches unclamped)
 // Blocks above 64 KiB are coded in windows (EncArgs::win0): the pairs of one window of all blocks take at most this much ...
 #ifndef REDUX_COOP_WINDOW_MIB // (A/B builds set these)
-#define REDUX_COOP_WINDOW_MIB 1408
+#define REDUX_COOP_WINDOW_MIB 2816
 #endif
 #ifndef REDUX_COOP_MAX_LARGE_BLOCKS
 #define REDUX_COOP_MAX_LARGE_BLOCKS 24576
@@ -76,15 +76,16 @@ __device__ __forceinline__ uint32_t coop_wave_scan(uint32_t v, uint32_t lane)
 // of THIS window only, at most kCoopWindowMax of them --, and what the windows before it counted comes from a table of the
 // block in LDS: bcum[s] = the symbols < s among them (cbase: the counts themselves, carried in the workspace).  32 KiB + 1 KiB
 // per block: four blocks per CU in flight, as for blocks of up to 64 KiB (u32 nodes: two).
+constexpr uint32_t kCoopModelDwords = Tree<true>::kDwords + 260; // the lanes' trees + bcum
+// (the body of the kernel: k_coop_step runs it next to the chain of the window before; ONE wave, lds = kCoopModelDwords)
 template <bool WINB>
-__global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
+__device__ __forceinline__ void coop_model_body(const EncArgs &a, uint2 *pairs, const uint64_t ent, uint32_t *lds)
 {
     constexpr bool U16 = true;
     typedef Tree<U16> TreeT;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[TreeT::kDwords + (WINB ? 260 : 0)];
     uint32_t *const bcum = lds + TreeT::kDwords; // WINB: 257 entries
     const uint32_t lane = threadIdx.x;
-    const uint64_t ent  = blockIdx.x; // the slot: lane ent & 63 of chain wave ent >> 6
+    // ent: the slot -- lane ent & 63 of chain wave ent >> 6
     const uint8_t *src;
     uint32_t       len;
     if (a.table) {
@@ -237,6 +238,13 @@ __global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
     }
 }
 
+template <bool WINB>
+__global__ void __launch_bounds__(64) k_coop_model(EncArgs a, uint2 *pairs)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kCoopModelDwords];
+    coop_model_body<WINB>(a, pairs, blockIdx.x, lds);
+}
+
 // ======================================================================================
 // The chain.  compress_symbol (codec.rs:55-89) has two halves that only talk one way: the interval (low, high -> the k
 // bits low and high now share, the j E3 steps, the next low and high) never looks at the bit writer, and the bit writer
@@ -360,16 +368,18 @@ __device__ __forceinline__ void emit_careful(EncState &S, uint32_t topk, uint32_
 // WIN: the launch codes one window of blocks that are coded window by window (every launch of blocks above 64 KiB); a lane
 // without a symbol in the window then sends EMPTY messages instead of coding a copy of a neighbour's symbols -- its slot may
 // hold a block that ended in an earlier window -- and stores nothing at all, so linear slots need no spare one.
-template <bool CB32, bool FIXUP, bool LINEAR = false, bool WIN = LINEAR>
-__global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pairs)
+constexpr uint32_t kCoopChainDwords = kCoopRing / 4 + 128; // the ring + fin
+// (the body of the kernel; bid: the workgroup's group of 64 blocks; lds = kCoopChainDwords, 16-byte aligned)
+template <bool CB32, bool FIXUP, bool LINEAR, bool WIN>
+__device__ __forceinline__ void coop_chain_body(const EncArgs &a, const uint2 *pairs, const uint32_t bid, uint32_t *lds)
 {
     static_assert(WIN || !LINEAR, "linear slots: blocks above 64 KiB, coded in windows");
     constexpr int ST = LINEAR ? (4 | kSwapped) : kPairStride;
-    __shared__ uint2 ring[kCoopRing / 8];
-    __shared__ uint2 fin[64]; // (low after the EOF symbol, its shifts): what encode_finish needs from the chain
+    uint2 *const ring = reinterpret_cast<uint2 *>(lds);
+    uint2 *const fin  = ring + kCoopRing / 8; // [64] (low after the EOF symbol, its shifts): what encode_finish needs from the chain
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t blk0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t blk0 = (uint64_t)bid * 64;
     const uint64_t blk  = blk0 + lane;
     const bool     has  = blk < a.nblocks && !(a.table && a.table[blk].index == kIdleEntry);
     const uint8_t *wsrc;
@@ -408,7 +418,7 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
         const uint32_t col  = live ? lane : (uint32_t)__builtin_ctzll(lives);
         // the pairs: rows of 64 lanes per symbol and group (blocks of up to 64 KiB), or block-major (WIN: k_coop_model)
         const uint2 *pg = WIN ? pairs + (blk0 + col) * coop_block_pitch(a.winlen)
-                              : pairs + (uint64_t)blockIdx.x * ((uint64_t)a.winlen + kCoopSlack) * 64 + col;
+                              : pairs + (uint64_t)bid * ((uint64_t)a.winlen + kCoopSlack) * 64 + col;
         auto load16 = [&](uint2 (&d)[16], uint32_t p) { // (up to 47 symbols past the last chunk: inside the slack)
             if (WIN) { // a chunk is one 128-byte line of the lane's block (the pitch is even, p a multiple of 16)
                 const uint4 *q = reinterpret_cast<const uint4 *>(pg + p);
@@ -519,7 +529,7 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
     }
 
     // ---------------- emit wave ----------------
-    uint8_t       *wdst  = LINEAR ? a.slots : a.slots + (uint64_t)blockIdx.x * (64 * a.slot_bytes + 128);
+    uint8_t       *wdst  = LINEAR ? a.slots : a.slots + (uint64_t)bid * (64 * a.slot_bytes + 128);
     const uint32_t off0  = LINEAR ? (live ? lane : 0u) * (uint32_t)a.slot_bytes : lane * 4u; // (LINEAR: a lane that is not live never stores)
     const uint32_t limit = LINEAR ? off0 + (a.slot_cap & ~3u) : off0 + (a.slot_cap / 4u) * 256u;
     constexpr uint32_t kChunkBudget = (16 * 4 + 32) * (stride_of<ST> / 4);
@@ -596,6 +606,32 @@ __global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pair
     if (stp && eofq == 0xFFFFFFFFu) { // the block goes on in the next window
         stp[3] = S.pend; stp[4] = S.nb; stp[5] = S.off;
         stp[6] = (uint32_t)S.acc; stp[7] = (uint32_t)(S.acc >> 32);
+    }
+}
+
+template <bool CB32, bool FIXUP, bool LINEAR = false, bool WIN = LINEAR>
+__global__ void __launch_bounds__(128) k_coop_chain(EncArgs a, const uint2 *pairs)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kCoopChainDwords];
+    coop_chain_body<CB32, FIXUP, LINEAR, WIN>(a, pairs, blockIdx.x, lds);
+}
+
+// One window's chain NEXT TO the model of the window after it (blocks coded in windows): workgroups [0, cgrid) are chain
+// workgroups of window w over the pairs the launch before left in pc, the others run the model of window w + 1 -- one wave
+// each, the second returns at once -- into the other pairs buffer.  Nothing in the launch depends on anything else in it; the
+// chain workgroups have the low numbers, so they are dispatched first.  Both roles take ~33 KiB of LDS: four workgroups per
+// CU in any mix.
+template <bool CB32, bool FIXUP, bool LINEAR>
+__global__ void __launch_bounds__(128) k_coop_step(EncArgs ac, EncArgs am, const uint2 *pc, uint2 *pm, uint32_t cgrid)
+{
+    constexpr uint32_t kDwords = kCoopChainDwords > kCoopModelDwords ? kCoopChainDwords : kCoopModelDwords;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kDwords];
+    if (blockIdx.x < cgrid) {
+        coop_chain_body<CB32, FIXUP, LINEAR, true>(ac, pc, blockIdx.x, lds);
+    } else {
+        if (threadIdx.x >= 64)
+            return;
+        coop_model_body<true>(am, pm, blockIdx.x - cgrid, lds);
     }
 }
 

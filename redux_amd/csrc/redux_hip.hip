@@ -288,7 +288,7 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
     g.coop_win  = block_size + 1;
     g.coop_nwin = 1;
     if (!g.u16) {
-        uint64_t w = kCoopWindowBytes / (8 * lanes_total);
+        uint64_t w = kCoopWindowBytes / 2 / (8 * lanes_total); // (two buffers: the model of a window runs next to the chain of the one before)
         w = w > kCoopWindowMax ? kCoopWindowMax : w;
         w = w < 4096 ? 4096 : w;
         if (w < (uint64_t)block_size + 1) {
@@ -296,14 +296,14 @@ static Geometry geometry(const redux_params *p, uint64_t in_len, uint32_t block_
             g.coop_win  = (uint32_t)((((uint64_t)block_size + 1 + g.coop_nwin - 1) / g.coop_nwin + 31) & ~31ull);
         }
     }
-    const uint64_t pair_bytes = (g.u16 ? lanes_total * ((uint64_t)g.coop_win + kCoopSlack) : lanes_total * coop_block_pitch(g.coop_win)) * 8;
+    const uint64_t pair_bytes = (g.u16 ? lanes_total * ((uint64_t)g.coop_win + kCoopSlack) : 2 * lanes_total * coop_block_pitch(g.coop_win)) * 8;
     // fewer than 64 large blocks on the small-grid kernels: linear slots, one per block (a row-major group area is 64 slots
     // big whatever the number of blocks: 230 MiB to code one 3 MiB stream); a lane addresses its slot with 32-bit offsets
     const bool linear = g.nblocks < 64 && !g.u16;
     g.coop = allow_coop && !static_model && !g.any && !g.gen && g.nblocks <= (g.u16 ? kCoopMaxBlocks : kCoopMaxLargeBlocks) && block_size >= kCoopMinBlock &&
-             (linear ? g.nblocks : 64ull) * g.slot_bytes < (1ull << 32) && pair_bytes <= kCoopMaxPairBytes;
-    if (g.coop) // the reciprocals of one window (+ what the chain wave reads ahead)
-        g.rc_n = g.coop_win + 64;
+             (linear ? g.nblocks : 64ull) * g.slot_bytes < (1ull << 32) && pair_bytes <= (g.u16 ? kCoopMaxPairBytes : kCoopWindowBytes + (64ull << 20));
+    if (g.coop) // the reciprocals of one window (+ what the chain wave reads ahead); blocks coded in windows: of two, alternating
+        g.rc_n = g.u16 ? g.coop_win + 64 : 2 * ((g.coop_win + 64 + 31) & ~31u);
     g.coop_linear = g.coop && linear;
     g.off_rc    = 0;
     g.off_sizes = align_up(g.off_rc + (uint64_t)g.rc_n * 8, 256);
@@ -684,39 +684,51 @@ static int encode_slots_impl(const redux_params *p, const void *d_in, uint64_t i
         a.winlen = g.coop_win;
         a.cstate = !g.u16 ? (uint32_t *)(ws + g.off_cstate) : nullptr;
         a.cbase  = a.cstate ? a.cstate + g.nblocks * 8 : nullptr;
-        // the longest block of the launch: its EOF symbol (symbol number `length`) is the last one coded
-        const uint64_t longest = d_table ? block_size : (in_len < block_size ? in_len : block_size);
-        for (uint32_t w = 0; w < g.coop_nwin && (uint64_t)w * g.coop_win <= longest; w++) {
-            a.win0 = w * g.coop_win;
-            if (w) // (the first window's table was filled above)
-                k_fill_rc_from<<<(g.rc_n + 255) / 256, 256, 0, s>>>((double *)(ws + g.off_rc), g.rc_n, 257u + a.win0);
-            if (g.u16) // whole blocks / one window of larger ones
-                k_coop_model<false><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
-            else
-                k_coop_model<true><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
-            if (g.coop_linear) {
-                if (g.fixup) {
-                    if (cb32) k_coop_chain<true, true, true><<<cgrid, 128, 0, s>>>(a, pairs);
-                    else      k_coop_chain<false, true, true><<<cgrid, 128, 0, s>>>(a, pairs);
-                } else {
-                    if (cb32) k_coop_chain<true, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
-                    else      k_coop_chain<false, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
-                }
-            } else if (!g.u16) { // 64 and more blocks above 64 KiB: row-major group areas, coded in windows
-                if (g.fixup) {
-                    if (cb32) k_coop_chain<true, true, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
-                    else      k_coop_chain<false, true, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
-                } else {
-                    if (cb32) k_coop_chain<true, false, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
-                    else      k_coop_chain<false, false, false, true><<<cgrid, 128, 0, s>>>(a, pairs);
-                }
-            } else if (g.fixup) {
+        if (g.u16) { // whole blocks
+            k_coop_model<false><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, pairs);
+            if (g.fixup) {
                 if (cb32) k_coop_chain<true, true><<<cgrid, 128, 0, s>>>(a, pairs);
                 else      k_coop_chain<false, true><<<cgrid, 128, 0, s>>>(a, pairs);
             } else {
                 if (cb32) k_coop_chain<true, false><<<cgrid, 128, 0, s>>>(a, pairs);
                 else      k_coop_chain<false, false><<<cgrid, 128, 0, s>>>(a, pairs);
             }
+            break;
+        }
+        // Blocks above 64 KiB, window by window.  Window w's chain runs in ONE launch with window w + 1's model (k_coop_step):
+        // two pairs buffers and two reciprocal tables, alternating.  The longest block of the launch decides the number of
+        // windows: its EOF symbol (symbol number `length`) is the last one coded.
+        const uint64_t longest = d_table ? block_size : (in_len < block_size ? in_len : block_size);
+        const uint32_t rc_half = g.rc_n / 2;
+        const uint64_t pair_half = g.nblocks * coop_block_pitch(g.coop_win);
+        double        *rcs[2] = {(double *)(ws + g.off_rc), (double *)(ws + g.off_rc) + rc_half};
+        uint2         *prs[2] = {pairs, pairs + pair_half};
+        k_coop_model<true><<<(uint32_t)g.nblocks, 64, 0, s>>>(a, prs[0]); // (win0 = 0)
+        for (uint32_t w = 0; w < g.coop_nwin && (uint64_t)w * g.coop_win <= longest; w++) {
+            EncArgs ac = a, am = a;
+            ac.win0 = w * g.coop_win;
+            ac.rc   = rcs[w & 1];
+            am.win0 = (w + 1) * g.coop_win;
+            // (the table of the first window was filled above, as k_fill_rc fills it, in the first half)
+            if (w)
+                k_fill_rc_from<<<(rc_half + 255) / 256, 256, 0, s>>>(rcs[w & 1], rc_half, 257u + ac.win0);
+            const bool more = w + 1 < g.coop_nwin && (uint64_t)am.win0 <= longest; // (a window that only holds EOF symbols has no model)
+            const uint2 *pc = prs[w & 1];
+            uint2       *pm = prs[(w + 1) & 1];
+            const uint32_t sgrid = cgrid + (uint32_t)g.nblocks;
+#define REDUX_COOP_LAUNCH(CB, FX, LIN)                                                                                 \
+    do {                                                                                                               \
+        if (more) k_coop_step<CB, FX, LIN><<<sgrid, 128, 0, s>>>(ac, am, pc, pm, cgrid);                               \
+        else      k_coop_chain<CB, FX, LIN, true><<<cgrid, 128, 0, s>>>(ac, pc);                                       \
+    } while (0)
+            if (g.coop_linear) {
+                if (g.fixup) { if (cb32) REDUX_COOP_LAUNCH(true, true, true); else REDUX_COOP_LAUNCH(false, true, true); }
+                else         { if (cb32) REDUX_COOP_LAUNCH(true, false, true); else REDUX_COOP_LAUNCH(false, false, true); }
+            } else {
+                if (g.fixup) { if (cb32) REDUX_COOP_LAUNCH(true, true, false); else REDUX_COOP_LAUNCH(false, true, false); }
+                else         { if (cb32) REDUX_COOP_LAUNCH(true, false, false); else REDUX_COOP_LAUNCH(false, false, false); }
+            }
+#undef REDUX_COOP_LAUNCH
         }
         break;
     }

@@ -90,14 +90,14 @@ def test_small_launches_get_a_pairs_area_and_their_own_kernels():
     assert b"k_coop" not in L.redux_encode_kernel_name(C.byref(p), None, 10 * 512, 512)          # blocks below 1 KiB
     assert b"k_coop" in L.redux_encode_kernel_name(C.byref(p), None, 1 << 20, 1 << 20)           # ONE block of any length (redux_compress): u32 nodes
     assert L.redux_encode_workspace_bytes(C.byref(p), 1 << 20, 1 << 20) < (1 << 20) * 90         # ... its pairs in rows of one lane, not 64
-    # blocks above 64 KiB are coded in windows of at most 65,504 symbols: the pairs area holds one window of every block (at most
-    # 1408 MiB), whatever the block length -- 2048 blocks of 1 MiB, and ONE stream of 1 GiB (whole blocks would ask for 16 and
+    # blocks above 64 KiB are coded in windows of at most 65,504 symbols: the pairs area holds one window of every block (two of them, at most
+    # 2816 MiB in all), whatever the block length -- 2048 blocks of 1 MiB, and ONE stream of 1 GiB (whole blocks would ask for 16 and
     # 8 GiB of pairs, + 8 GiB of reciprocals) -- and such launches take the small-grid kernels up to 24,576 blocks
     assert b"k_coop" in L.redux_encode_kernel_name(C.byref(p), None, 2048 << 20, 1 << 20)
     slot = L.redux_encode_slot_bytes(C.byref(p), 1 << 20)
-    assert L.redux_encode_workspace_bytes(C.byref(p), 2048 << 20, 1 << 20) < 2049 * (slot + 256) + (1100 << 20)
+    assert L.redux_encode_workspace_bytes(C.byref(p), 2048 << 20, 1 << 20) < 2049 * (slot + 256) + (2100 << 20)
     assert b"k_coop" in L.redux_encode_kernel_name(C.byref(p), None, 1 << 30, 1 << 30)
-    assert L.redux_encode_workspace_bytes(C.byref(p), 1 << 30, 1 << 30) < L.redux_encode_slot_bytes(C.byref(p), 1 << 30) + (4 << 20)
+    assert L.redux_encode_workspace_bytes(C.byref(p), 1 << 30, 1 << 30) < L.redux_encode_slot_bytes(C.byref(p), 1 << 30) + (8 << 20)
     assert b"k_coop" in L.redux_encode_kernel_name(C.byref(p), None, 24576 << 17, 1 << 17)
     assert b"k_coop" not in L.redux_encode_kernel_name(C.byref(p), None, 24577 << 17, 1 << 17)
     assert b"k_coop" not in L.redux_encode_kernel_name(C.byref(_lib.Params(12, 20, 32)), None, 62 * BS, BS)

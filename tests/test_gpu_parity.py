@@ -1404,7 +1404,7 @@ def test_small_grid_kernels_on_large_blocks(rx):
 
 def _coop_window(nentries, block_size):
     """geometry() of redux_hip.hip: the window (symbols) the small-launch kernels code a launch of large blocks in."""
-    w = max(4096, min(65504, (1408 << 20) // (8 * nentries)))
+    w = max(4096, min(65504, (2816 << 20) // 2 // (8 * nentries)))  # (two buffers of pairs)
     if w >= block_size + 1:
         return block_size + 1, 1
     nwin = (block_size + 1 + w - 1) // w
@@ -1443,7 +1443,7 @@ def test_small_grid_kernels_code_long_blocks_in_windows(rx, params, bs, nfull):
     assert win2 == win and nwin >= 2, (win, win2, nwin)
     assert b"k_coop_model" in L.redux_encode_kernel_name(C.byref(cp), None, ne * bs, bs)
     # (the slots, and one window of pairs per entry + change: whole blocks would take 8 bytes of pairs per input byte of every entry)
-    assert L.redux_encode_workspace_bytes(C.byref(cp), ne * bs, bs) < (ne + 65) * (L.redux_encode_slot_bytes(C.byref(cp), bs) + 256) + ne * 66000 * 8 + (8 << 20)
+    assert L.redux_encode_workspace_bytes(C.byref(cp), ne * bs, bs) < (ne + 65) * (L.redux_encode_slot_bytes(C.byref(cp), bs) + 256) + 2 * ne * 66000 * 8 + (8 << 20)
     text = open(os.path.join(GOLDEN, "corpora", "large", "world192.txt"), "rb").read()
     datas = []
     for i, n in enumerate(lens):
