@@ -1513,6 +1513,14 @@ def test_wave_decoder_on_damaged_large_blocks(rx, params):
     _damaged_large_blocks(rx, params, 150_000, 0, b"k_decode_wave")
 
 
+@pytest.mark.parametrize("params", [(8, 30, 32), (8, 14, 16)])
+def test_wave_decoder_with_staged_output(rx, params):
+    """... and with more than 256 blocks of 1 MiB or more -- hundreds of streams a page apart -- its instance that collects 64
+    symbols across the lanes and stores them as one run (k_decode_wave<.., STAGE>): the same checks, 300 short streams in
+    front of the damaged ones, so every partial last run (0 ... 39 symbols) and whole runs of 64 occur."""
+    _damaged_large_blocks(rx, params, 1 << 20, 300, b"k_decode_wave")
+
+
 @pytest.mark.parametrize("params,cap", [((8, 30, 32), 150_000), ((8, 30, 32), 100_000), ((8, 22, 24), 150_000), ((8, 14, 16), 100_000), ((8, 16, 18), 150_000)])
 def test_cell_decoder_on_damaged_large_blocks(rx, params, cap):
     """... and in launches of more than 1024 blocks they run on the cell decoder with u32 nodes (k_decode_cells<8>,
