@@ -134,7 +134,6 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
     const uint8_t *sp          = a.in + o0;
     const uint64_t stream_bits = size * 8;
     uint8_t       *dst         = a.out + dst_off;
-    const rc_ptr   rcp         = (rc_ptr)a.rc;
 
     // the model: inclusive prefix sums of the 256 data symbols' frequencies (all 1 at the start), four consecutive
     // symbols to a lane; EOF sits above them
@@ -159,9 +158,8 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
     // (bitio/mod.rs:107), no room for the decoded symbol (codec.rs:171) -- leave the loop by ONE rarely taken branch; a taken
     // branch costs a lone wave ~35 cycles and every scalar instruction an issue slot, so the loop has no other exits.  (An
     // EOF step's garbage is harmless: its "symbol" is 256, which the update ignores, and nothing of it is committed.)
-    double   rc_next = rcp[0]; // the reciprocal of step p + 1 is loaded during step p (a lone wave hides no latency by itself)
-    double   rcv     = 0.0;         // past the table: lane l holds the reciprocal of count 257 + rbase + l
-    uint32_t rbase   = 0xFFFFFF00u; // (no such base: the first step past the table computes its 64)
+    double   rcv     = 0.0;         // lane l holds the reciprocal of count 257 + rbase + l
+    uint32_t rbase   = 0xFFFFFF00u; // (no such base: the first step computes its 64)
     uint32_t p       = 0;
     bool     eof = false, dry = false;
     // stream bits not pulled yet, as a 32-bit count-down (a block is below 4 GiB, so stream_bits < 2^35: the count-down is
@@ -174,25 +172,23 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
     if (!done) {
         for (;; p++) {
             const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
-            double         rc  = rc_next;
-            if (__builtin_expect(nup >= a.rc_n, 0)) {
-                // past the table's window: the reciprocals of 64 consecutive counts at a time, one per lane, each computed as
-                // k_fill_rc computes an entry (the correctly rounded quotient, biased up 4 ulp) -- ONE division sequence per 64
-                // steps -- and this step's picked out by two v_readlane (a division per step: 432.5 ns per symbol over a 4 MiB block, this: 427.7)
-                if (nup - rbase >= 64u) { // (wave-uniform)
-                    rbase          = nup & ~63u;
-                    const double r = 1.0 / (double)(257u + rbase + lane);
-                    rcv            = __longlong_as_double(__double_as_longlong(r) + 4);
-                }
-                const uint32_t       li = nup - rbase;
-                const unsigned long long rb = (unsigned long long)__double_as_longlong(rcv);
-                const uint32_t       lo_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rb, (int)li);
-                const uint32_t       hi_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rb >> 32), (int)li);
-                rc = __longlong_as_double((long long)(((unsigned long long)hi_ << 32) | lo_));
+            // This step's reciprocal (what k_fill_rc would hold for it: the correctly rounded 1 / count, biased up 4 ulp --
+            // scale_div's proof needs a value in that range).  No table: lane l of rcv holds the reciprocal of count
+            // 257 + rbase + l, all 64 computed by ONE division sequence every 64 steps, and a step picks its own with two
+            // v_readlane -- no load in the step, nothing to wait for, the same cost at any block length (378 ns per symbol; a table of 2^20
+            // entries read by a scalar load per step, with a division per step behind it: 408 inside the table, 431 over a 4 MiB block).
+            if (__builtin_expect(nup - rbase >= 64u, 0)) { // (wave-uniform)
+                rbase          = nup & ~63u;
+                const double r = 1.0 / (double)(257u + rbase + lane);
+                rcv            = __longlong_as_double(__double_as_longlong(r) + 4);
             }
-            {   // (the load is unconditional -- its index clamped into the table -- and nothing waits for it before the next step)
-                const uint32_t nx = p + 1 < a.nfreeze ? p + 1 : a.nfreeze;
-                rc_next           = rcp[nx < a.rc_n ? nx : a.rc_n];
+            double rc;
+            {
+                const uint32_t           li  = nup - rbase;
+                const unsigned long long rb  = (unsigned long long)__double_as_longlong(rcv);
+                const uint32_t           lo_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rb, (int)li);
+                const uint32_t           hi_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rb >> 32), (int)li);
+                rc = __longlong_as_double((long long)(((unsigned long long)hi_ << 32) | lo_));
             }
             const uint32_t c   = 257u + nup;
             // value = ((pending - low + 1) * count - 1) / range      (codec.rs:129-131)

@@ -489,7 +489,7 @@ const char *redux_decode_kernel_name_n(const redux_params *p, const void *d_out,
     if (check_params(p) != REDUX_OK || block_size == 0)
         return "";
     (void)d_out; // every decoder takes any alignment (it only picks the store width inside the kernel)
-    const Geometry g = geometry(p, block_size, block_size);
+    const Geometry g = geometry(p, block_size, block_size, false, false); // (a decoder: no small-grid encoder, whose windows would size the reciprocal table)
     switch (pick_decode_kernel(g, p, nblocks, block_size)) {
     case DecKernel::LockCb32: return "k_decode_lock<true> (u16 tree, one wave per 64 blocks, code_bits 32)";
     case DecKernel::Lock: return "k_decode_lock<false> (u16 tree, one wave per 64 blocks)";
@@ -950,7 +950,7 @@ uint64_t redux_decode_workspace_bytes(const redux_params *p, uint64_t nblocks, u
 {
     if (check_params(p) != REDUX_OK || block_size == 0)
         return 0;
-    const Geometry g = geometry(p, block_size, block_size);
+    const Geometry g = geometry(p, block_size, block_size, false, false); // (a decoder: no small-grid encoder, whose windows would size the reciprocal table)
     if (g.gen) // (11- and 12-bit symbols: the bottom cells of the decoder's tree live in the workspace: gen_decode_in_workspace)
         return align_up((uint64_t)g.rc_n * 8, 256) +
                (gen_decode_cells(p, block_size) && gen_decode_in_workspace(p, nblocks) ? (nblocks + 63) / 64 * 64 * gen_decode_tree_bytes(p) : 0);
@@ -979,7 +979,7 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
         return REDUX_OK;
     if (!d_table && out_cap < nblocks * (uint64_t)block_size)
         return REDUX_OUTPUT_TOO_SMALL;
-    const Geometry g = geometry(p, block_size, block_size);
+    const Geometry g = geometry(p, block_size, block_size, false, false); // (a decoder: no small-grid encoder, whose windows would size the reciprocal table)
     if (workspace_bytes < redux_decode_workspace_bytes(p, nblocks, block_size))
         return REDUX_OUTPUT_TOO_SMALL;
     if (d_table && (g.gen || g.any))

@@ -18,6 +18,8 @@ SHAPES = (("iid", 1 << 20, 1), ("zipf", 1 << 20, 1), ("iid", 1 << 20, 16), ("iid
           ("zipf", 4 << 20, 1))  # (the last one: three quarters of it past the reciprocal table's window of 2^20 entries)
 if len(sys.argv) > 1:  # tools/measure_wave.py zipf,4194304,1 ...
     SHAPES = tuple((a.split(",")[0], int(a.split(",")[1]), int(a.split(",")[2])) for a in sys.argv[1:])
+# REDUX_MEASURE_PAD=<bytes>: allocate that much first, so that every buffer of the measurement lands elsewhere (placement check)
+_pad = torch.empty(int(os.environ.get("REDUX_MEASURE_PAD", "0")) or 1, dtype=torch.uint8, device="cuda")
 for kind, bs, nb in SHAPES:
     n = bs * nb
     d_in = (rx.gen_iid if kind == "iid" else rx.gen_zipf)(n)
