@@ -30,8 +30,10 @@ namespace redux {
 #ifndef REDUX_WAVE_DEC_MAX_BLOCKS // (A/B builds set it)
 #define REDUX_WAVE_DEC_MAX_BLOCKS 1024
 #endif
-constexpr uint64_t kWaveStageBlocks    = 256;     // more blocks than this ...
-constexpr uint32_t kWaveStageBlockSize = 1u << 20; // ... of at least this size: k_decode_wave<.., STAGE>
+// ... except launches of more than kWaveDecManyBlocks blocks of kWaveDecLargeBlock bytes or more: 1024 waves over streams of
+// 1 MiB and more run at 547 ns per symbol (768: 415; 1024 x 128 KiB: 401), k_decode_cells<8> at 479 (profiles/r04_wave_decoder.txt)
+constexpr uint64_t kWaveDecManyBlocks = 768;
+constexpr uint32_t kWaveDecLargeBlock = 1u << 20;
 constexpr uint64_t kWaveDecMaxBlocks = REDUX_WAVE_DEC_MAX_BLOCKS; // one wave per SIMD: beyond that the waves share SIMDs and the lock-step decoder wins
 
 // The bit reader of a wave that decodes ONE stream (bitio/mod.rs:78-120): the stream comes in rows of 64 dwords -- lane l
@@ -109,9 +111,7 @@ struct WaveBits {
     }
 };
 
-// STAGE: the launch has hundreds of streams a page or more apart (kWaveStageBlocks, kWaveStageBlockSize): the symbols leave
-// 64 at a time instead of one byte per step (below).
-template <bool FIXUP, bool STAGE = false>
+template <bool FIXUP>
 __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
 {
     const uint32_t lane = threadIdx.x;
@@ -168,7 +168,6 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
     uint32_t left = rest > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)rest;
     rest -= left;
     uint32_t n = 0;
-    uint32_t ob = 0; // output staging: lane l holds the symbol of step (p & ~63) + l
     if (!done) {
         for (;; p++) {
             const uint32_t nup = p < a.nfreeze ? p : a.nfreeze;
@@ -275,26 +274,11 @@ __global__ void __launch_bounds__(64) k_decode_wave(DecArgs a)
             W = ((h2 & 0x7FFFFFFFu) | (h1 & 0x80000000u)) & (0xFFFFFFFFu << sh);
             B.skip(n);
             // emit the symbol (write_bits(symbol, 8), codec.rs:171): every lane stores the same byte to the same address (no
-            // exec mask, no branch around it: the requests merge; a byte per ~700 cycles is nothing to the memory system) --
-            // for ONE stream.  1024 streams 2 MiB apart, each storing single bytes, ran at 586 ns per symbol instead of 420:
-            // STAGE puts the symbol into lane p & 63 of a staging register (one v_writelane) and every 64 steps the 64
-            // lanes store their bytes as one 64-byte run: 449 ns there, and 431 instead of 421 for one stream, hence the choice.
-            if (STAGE) {
-                // (the lane select through m0: a gfx9 VOP3 reads one SGPR besides it, and this clang has no writelane builtin.
-                //  Nothing else in the library's device code touches m0 -- checked in the ISA --, so the "reserved register"
-                //  diagnostic about the clobber is moot here.)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-                asm volatile("s_and_b32 m0, %2, 63\n\tv_writelane_b32 %0, %1, m0" : "+v"(ob) : "s"(s), "s"(p) : "m0", "scc");
-#pragma clang diagnostic pop
-                if ((p & 63u) == 63u)
-                    dst[(p & ~63u) + lane] = (uint8_t)ob;
-            } else {
-                dst[p] = (uint8_t)s;
-            }
+            // exec mask, no branch around it: the requests merge; a byte per ~700 cycles is nothing to the memory system.
+            // Staging 64 symbols across the lanes and storing them as one run was built and measured: +1-2 % for one
+            // stream and no gain for many, profiles/r04_wave_decoder.txt)
+            dst[p] = (uint8_t)s;
         }
-        if (STAGE && lane < (p & 63u)) // the committed steps of the last, partial run
-            dst[(p & ~63u) + lane] = (uint8_t)ob;
         // bits pulled when the loop was left: the steps before this one, plus -- unless it ended on the EOF symbol, which
         // returns before renormalising -- this step's own (its renormalisation was entered whichever way it failed)
         consumed = stream_bits - rest - left;

@@ -196,7 +196,7 @@ static bool cells8_takes(const redux_params *p, uint32_t block_size, uint64_t ns
 {
     // (nslots == 0: "a full grid", redux_decode_kernel_name)
     return p->symbol_bits == 8 && p->code_bits <= 32 && block_size > 65536 && block_size <= (1u << 22) &&
-           (nslots == 0 || nslots > kWaveDecMaxBlocks) && !table;
+           (nslots == 0 || nslots > kWaveDecMaxBlocks || (nslots > kWaveDecManyBlocks && block_size >= kWaveDecLargeBlock)) && !table;
 }
 static uint32_t cells8_rc_entries(const redux_params *p, uint32_t block_size)
 {
@@ -1124,18 +1124,8 @@ static int decode_blocks_dev_impl(const redux_params *p, const void *d_in, const
     a.rc_n       = rc_n - 32; // (the last 32 entries are slack for the lock-step decoder's look-ahead)
     const uint32_t grid = (uint32_t)((nblocks + 63) / 64);
     switch (pick_decode_kernel(g, p, nblocks)) {
-    case DecKernel::Wave:
-    case DecKernel::WaveFixup: {
-        const bool fx = pick_decode_kernel(g, p, nblocks) == DecKernel::WaveFixup;
-        if (nblocks > kWaveStageBlocks && block_size >= kWaveStageBlockSize) { // hundreds of streams a page apart: staged output
-            if (fx) k_decode_wave<true, true><<<(uint32_t)nblocks, 64, 0, s>>>(a);
-            else    k_decode_wave<false, true><<<(uint32_t)nblocks, 64, 0, s>>>(a);
-        } else {
-            if (fx) k_decode_wave<true><<<(uint32_t)nblocks, 64, 0, s>>>(a);
-            else    k_decode_wave<false><<<(uint32_t)nblocks, 64, 0, s>>>(a);
-        }
-        break;
-    }
+    case DecKernel::Wave: k_decode_wave<false><<<(uint32_t)nblocks, 64, 0, s>>>(a); break;
+    case DecKernel::WaveFixup: k_decode_wave<true><<<(uint32_t)nblocks, 64, 0, s>>>(a); break;
     case DecKernel::LockCb32: k_decode_lock<true><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::Lock: k_decode_lock<false><<<grid, 64, 0, s>>>(a); break;
     case DecKernel::GenericU16: k_decode<true, false><<<grid, 64, 0, s>>>(a); break;

@@ -975,7 +975,8 @@ def test_kernel_names_follow_the_dispatch(rx):
     assert dec((8, 30, 32), 1 << 23).startswith("k_decode<false, true>")                  # ... above 4 MiB: per-lane control flow
     cp8 = _lib.Params(8, 30, 32)
     name_n = lambda bs, nb: L.redux_decode_kernel_name_n(C.byref(cp8), None, bs, nb).decode()
-    assert name_n(1 << 20, 1024).startswith("k_decode_wave") and name_n(1 << 20, 1025).startswith("k_decode_cells<8>")
+    assert name_n(1 << 17, 1024).startswith("k_decode_wave") and name_n(1 << 17, 1025).startswith("k_decode_cells<8>")
+    assert name_n(1 << 20, 768).startswith("k_decode_wave") and name_n(1 << 20, 769).startswith("k_decode_cells<8>")  # (blocks of 1 MiB and more: from 769)
     assert enc((8, 3, 32), 0, 1, 1) == ""
 
 
@@ -1513,12 +1514,15 @@ def test_wave_decoder_on_damaged_large_blocks(rx, params):
     _damaged_large_blocks(rx, params, 150_000, 0, b"k_decode_wave")
 
 
-@pytest.mark.parametrize("params", [(8, 30, 32), (8, 14, 16)])
-def test_wave_decoder_with_staged_output(rx, params):
-    """... and with more than 256 blocks of 1 MiB or more -- hundreds of streams a page apart -- its instance that collects 64
-    symbols across the lanes and stores them as one run (k_decode_wave<.., STAGE>): the same checks, 300 short streams in
-    front of the damaged ones, so every partial last run (0 ... 39 symbols) and whole runs of 64 occur."""
-    _damaged_large_blocks(rx, params, 1 << 20, 300, b"k_decode_wave")
+def test_many_blocks_of_a_mebibyte_take_the_cell_decoder(rx):
+    """More than 768 blocks of 1 MiB or more: the wave decoder slows down there (547 ns per symbol at 1024 waves over such
+    streams against 401 over 128 KiB blocks), so the launch is the cell decoder's from 769 blocks on: the same checks, 800 short
+    streams in front of the damaged ones."""
+    import ctypes as C
+    from redux_amd import _lib
+    cp = _lib.Params(8, 30, 32)
+    assert b"k_decode_wave" in _lib.lib().redux_decode_kernel_name_n(C.byref(cp), None, 1 << 20, 768)
+    _damaged_large_blocks(rx, (8, 30, 32), 1 << 20, 800, b"k_decode_cells<8>")
 
 
 @pytest.mark.parametrize("params,cap", [((8, 30, 32), 150_000), ((8, 30, 32), 100_000), ((8, 22, 24), 150_000), ((8, 14, 16), 100_000), ((8, 16, 18), 150_000)])
